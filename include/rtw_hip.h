@@ -1,0 +1,135 @@
+/*
+ * rtw_hip.h -- C ABI of librtw_hip.so, the MI355X (gfx950) implementation of the hot path
+ *              render -> ray_color -> hit/scatter  of claforte/RayTracingWeekend.jl.
+ *
+ * The reference has NO FFI: its boundary for this path is the exported Julia function
+ *     render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=1) -> Matrix{RGB{T}}
+ * (/root/reference/src/render.jl:8-44, export at src/RayTracingWeekend.jl:25).  This header is
+ * what a Julia `ccall` shim for that function binds (julia/RTWeekendHIP.jl):
+ * plain pointers and sizes only, no torch / HIP types in any signature.
+ *
+ * Conventions
+ *   - every pointer is owned by the caller; the library reads inputs and writes outputs only
+ *     during the call and retains nothing (device-side handles excepted, see below);
+ *   - return 0 = OK, negative = argument/validation error, positive = hipError_t;
+ *     rtw_last_error() returns a thread-local message valid until the next call on that thread;
+ *   - never throws, never calls exit/abort;
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails.
+ */
+#ifndef RTW_HIP_H
+#define RTW_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTW_ABI_VERSION 1
+
+/* Material kinds: Lambertian / Metal / Dielectric (src/material.jl:3-5, 25-29, 37-39). */
+enum { RTW_LAMBERTIAN = 0, RTW_METAL = 1, RTW_DIELECTRIC = 2 };
+
+/* A HittableList of Sphere{T} (src/structs.jl:10,31-35) flattened to SoA.  Host pointers. */
+typedef struct {
+    int32_t n;
+    const float *cx, *cy, *cz, *r;   /* Sphere.center, Sphere.radius (may be negative)       */
+    const int32_t *kind;             /* RTW_* of Sphere.mat                                  */
+    const float *ar, *ag, *ab;       /* albedo (Lambertian, Metal)                           */
+    const float *param;              /* Metal.fuzz / Dielectric.ir / 0                       */
+} rtw_scene_f32;
+
+typedef struct {
+    int32_t n;
+    const double *cx, *cy, *cz, *r;
+    const int32_t *kind;
+    const double *ar, *ag, *ab;
+    const double *param;
+} rtw_scene_f64;
+
+/* Camera{T}: the 22 scalars in the field order of src/camera.jl:2-9. */
+typedef struct {
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    float lens_radius;
+} rtw_camera_f32;
+
+typedef struct {
+    double origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    double lens_radius;
+} rtw_camera_f64;
+
+/* Positional arguments of render() plus the keyword extras of the shim. */
+typedef struct {
+    int32_t width;        /* image_width  (src/render.jl:8)                                   */
+    int32_t height;       /* image_width div 16//9 (src/render.jl:11-12); computed by caller  */
+    int32_t spp;          /* n_samples    (src/render.jl:9)                                   */
+    int32_t max_depth;    /* ray_color depth; reference default 16 (src/ray_color.jl:14)      */
+    uint64_t seed;        /* render seed; the stream of (pixel, chunk) derives from it        */
+    int32_t n_chunks;     /* sample chunks per pixel, each with its own RNG stream;
+                             0 = default rule min(spp, 16).  Part of the image definition.    */
+    int32_t shard_index;  /* this call renders the 8x8 pixel tiles t with                      */
+    int32_t shard_count;  /*   t mod shard_count == shard_index; other pixels are written 0    */
+    int32_t device;       /* HIP device ordinal; -1 = current device                          */
+    int32_t gamma;        /* 1 = sqrt per channel (rgb_gamma2, src/vec.jl:22); 0 = linear mean */
+    int32_t flags;        /* reserved, must be 0                                              */
+} rtw_params;
+
+/* Counters of the most recent render on the calling thread's device context. */
+typedef struct {
+    uint64_t samples;       /* pixel samples taken by this shard                              */
+    uint64_t segments;      /* ray segments == closest-hit scans (src/hit.jl:38-50)           */
+    uint64_t sphere_tests;  /* segments * n spheres (src/hit.jl:12-35 evaluations)            */
+    double kernel_ms;       /* HIP-event time of the trace kernel (the dominant kernel)       */
+    double total_ms;        /* HIP-event time of the whole device-side render (all kernels)   */
+    int32_t n_chunks;       /* chunks per pixel actually used                                 */
+    int32_t grid_blocks;    /* trace kernel launch geometry                                   */
+    int32_t block_threads;
+    int32_t reserved;
+} rtw_stats_t;
+
+int rtw_abi_version(void);
+int rtw_device_count(int *count);
+const char *rtw_last_error(void);
+
+/* render(scene, cam, width, spp) for elem_type Float32 / Float64 -- replaces
+ * /root/reference/src/render.jl:8-44.  `out` is a HOST buffer of height*width*3 elements in
+ * the memory layout of the returned Matrix{RGB{T}}: pixel (i,j) (1-based row, column) at
+ * ((j-1)*height + (i-1))*3.  Blocking.  Uploads the scene, renders, copies the image back. */
+int rtw_render_f32(const rtw_scene_f32 *scene, const rtw_camera_f32 *cam, const rtw_params *p,
+                   float *out);
+int rtw_render_f64(const rtw_scene_f64 *scene, const rtw_camera_f64 *cam, const rtw_params *p,
+                   double *out);
+
+/* Device-resident variant of the same call for callers that keep the image in HBM (bench.py,
+ * multi-process sharding over RCCL).  `scene` is a handle from rtw_scene_upload_*; `d_out` is a
+ * DEVICE pointer to height*width*3 elements; `hip_stream` is a hipStream_t passed as void*
+ * (NULL = the null stream).  Asynchronous with respect to the host: work is enqueued on the
+ * stream; rtw_stats() synchronises with it. */
+typedef struct rtw_scene_dev *rtw_scene_handle;
+int rtw_scene_upload_f32(const rtw_scene_f32 *scene, int device, rtw_scene_handle *out);
+int rtw_scene_upload_f64(const rtw_scene_f64 *scene, int device, rtw_scene_handle *out);
+int rtw_scene_free(rtw_scene_handle scene);
+int rtw_render_device_f32(rtw_scene_handle scene, const rtw_camera_f32 *cam, const rtw_params *p,
+                          void *d_out, void *hip_stream);
+int rtw_render_device_f64(rtw_scene_handle scene, const rtw_camera_f64 *cam, const rtw_params *p,
+                          void *d_out, void *hip_stream);
+
+/* Counters/timings of the last render issued from this thread (waits for it to finish). */
+int rtw_stats(rtw_stats_t *out);
+
+/* Unit-level device entry points used by the parity tests (tier T0): each evaluates the
+ * device implementation of one reference function on `count` inputs, one lane per input.
+ * All pointers are HOST pointers; layouts are documented in tests/test_gpu_units.py.
+ *   op: 0 hit_sphere  1 reflect  2 refract  3 reflectance  4 scatter  5 get_ray  6 skycolor
+ *       7 rng_f (uniforms from a stream state)  8 hit_world                                  */
+int rtw_unit_f32(int op, int count, const void *in, void *out, const rtw_scene_f32 *scene,
+                 const rtw_camera_f32 *cam);
+int rtw_unit_f64(int op, int count, const void *in, void *out, const rtw_scene_f64 *scene,
+                 const rtw_camera_f64 *cam);
+
+/* Frees cached per-device workspaces.  Optional. */
+int rtw_shutdown(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,122 @@
+"""ctypes binding of librtw_hip.so (C ABI: include/rtw_hip.h).  No fallback of any kind."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librtw_hip.so")
+
+#: every symbol include/rtw_hip.h declares
+SYMBOLS = [
+    "rtw_abi_version", "rtw_device_count", "rtw_last_error", "rtw_render_f32", "rtw_render_f64",
+    "rtw_scene_upload_f32", "rtw_scene_upload_f64", "rtw_scene_free", "rtw_render_device_f32",
+    "rtw_render_device_f64", "rtw_stats", "rtw_unit_f32", "rtw_unit_f64", "rtw_shutdown",
+]
+
+
+def _scene_struct(ct):
+    class S(C.Structure):
+        _fields_ = [("n", C.c_int32)] + [(k, C.POINTER(ct)) for k in ("cx", "cy", "cz", "r")] + \
+                   [("kind", C.POINTER(C.c_int32))] + [(k, C.POINTER(ct)) for k in ("ar", "ag", "ab", "param")]
+    return S
+
+
+def _camera_struct(ct):
+    class Cam(C.Structure):
+        _fields_ = [(k, ct * 3) for k in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w")] + \
+                   [("lens_radius", ct)]
+    return Cam
+
+
+SceneF32, SceneF64 = _scene_struct(C.c_float), _scene_struct(C.c_double)
+CameraF32, CameraF64 = _camera_struct(C.c_float), _camera_struct(C.c_double)
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
+                ("seed", C.c_uint64), ("n_chunks", C.c_int32), ("shard_index", C.c_int32),
+                ("shard_count", C.c_int32), ("device", C.c_int32), ("gamma", C.c_int32), ("flags", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("n_chunks", C.c_int32),
+                ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+class RtwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librtw_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load librtw_hip.so; raise loudly if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C raytracingweekend.jl_amd/csrc`).  There is no CPU fallback for the render path.")
+    L = C.CDLL(LIB_PATH)
+    L.rtw_last_error.restype = C.c_char_p
+    L.rtw_abi_version.restype = C.c_int
+    for name in SYMBOLS:
+        getattr(L, name)  # AttributeError if the ABI is incomplete
+    L.rtw_scene_upload_f32.argtypes = [C.POINTER(SceneF32), C.c_int, C.POINTER(C.c_void_p)]
+    L.rtw_scene_upload_f64.argtypes = [C.POINTER(SceneF64), C.c_int, C.POINTER(C.c_void_p)]
+    L.rtw_scene_free.argtypes = [C.c_void_p]
+    L.rtw_render_device_f32.argtypes = [C.c_void_p, C.POINTER(CameraF32), C.POINTER(Params), C.c_void_p, C.c_void_p]
+    L.rtw_render_device_f64.argtypes = [C.c_void_p, C.POINTER(CameraF64), C.POINTER(Params), C.c_void_p, C.c_void_p]
+    L.rtw_render_f32.argtypes = [C.POINTER(SceneF32), C.POINTER(CameraF32), C.POINTER(Params), C.c_void_p]
+    L.rtw_render_f64.argtypes = [C.POINTER(SceneF64), C.POINTER(CameraF64), C.POINTER(Params), C.c_void_p]
+    L.rtw_stats.argtypes = [C.POINTER(Stats)]
+    L.rtw_unit_f32.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(SceneF32), C.POINTER(CameraF32)]
+    L.rtw_unit_f64.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(SceneF64), C.POINTER(CameraF64)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RtwError(rc, lib().rtw_last_error().decode("utf-8", "replace"))
+
+
+def is_f64(T):
+    return np.dtype(T) == np.float64
+
+
+def make_scene(flat, T):
+    """dict from structs.flatten_scene -> (ctypes struct, keep-alive list)"""
+    ct = C.c_double if is_f64(T) else C.c_float
+    S = (SceneF64 if is_f64(T) else SceneF32)()
+    keep = []
+    S.n = int(flat["n"])
+    for k in ("cx", "cy", "cz", "r", "ar", "ag", "ab", "param"):
+        a = np.ascontiguousarray(flat[k], dtype=T)
+        keep.append(a)
+        setattr(S, k, a.ctypes.data_as(C.POINTER(ct)))
+    kind = np.ascontiguousarray(flat["kind"], dtype=np.int32)
+    keep.append(kind)
+    S.kind = kind.ctypes.data_as(C.POINTER(C.c_int32))
+    return S, keep
+
+
+def make_camera(cam, T):
+    ct = C.c_double if is_f64(T) else C.c_float
+    Cm = (CameraF64 if is_f64(T) else CameraF32)()
+    for k in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w"):
+        setattr(Cm, k, (ct * 3)(*[float(x) for x in np.asarray(getattr(cam, k), dtype=T)]))
+    Cm.lens_radius = float(np.dtype(T).type(cam.lens_radius))
+    return Cm
+
+
+def make_params(width, height, spp, max_depth=16, seed=1, n_chunks=0, shard_index=0, shard_count=1,
+                device=-1, gamma=1):
+    return Params(int(width), int(height), int(spp), int(max_depth), int(seed), int(n_chunks),
+                  int(shard_index), int(shard_count), int(device), int(gamma), 0)

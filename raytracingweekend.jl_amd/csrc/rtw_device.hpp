@@ -1,0 +1,250 @@
+// rtw_device.hpp -- device-side building blocks of the hot path, gfx950 (MI355X) only.
+//
+// Each function restates one reference function (paths relative to /root/reference) under the
+// numerics contract of DESIGN.md section 4: IEEE binary32/64, one rounding per written
+// operation (this file is compiled with -ffp-contract=off), explicit FMA only in the
+// ray-sphere discriminant.  Float32 mode is the reference's mixed precision:
+// geometry / RNG / scatter in T, sky colour, throughput and accumulation in double.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtw {
+
+enum { LAMBERTIAN = 0, METAL = 1, DIELECTRIC = 2 };
+
+template <typename T> struct V3 { T x, y, z; };
+struct C3 { double r, g, b; };
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<double> { using type = double4; };
+
+__device__ __forceinline__ float t_sqrt(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ double t_sqrt(double x) { return __builtin_sqrt(x); }
+__device__ __forceinline__ float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ---- SVector arithmetic (src/vec.jl:3): element-wise, one rounding each ---------------------
+template <typename T> __device__ __forceinline__ V3<T> vadd(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> vsub(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> vscale(T s, V3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <typename T> __device__ __forceinline__ V3<T> vneg(V3<T> a) { return {-a.x, -a.y, -a.z}; }
+// StaticArrays dot, length 3: (a1*b1 + a2*b2) + a3*b3
+template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// StaticArrays normalize(v) = inv(norm(v)) * v
+template <typename T> __device__ __forceinline__ V3<T> normalize(V3<T> a) {
+    T inv = T(1) / t_sqrt(dot(a, a));
+    return vscale(inv, a);
+}
+// src/vec.jl:19-20: compared against the Float64 literal 1e-5
+template <typename T> __device__ __forceinline__ bool near_zero(V3<T> a) { return (double)dot(a, a) < 1e-5; }
+
+// ---- RNG: per-lane Xoroshiro128+ (src/init.jl:2-12, src/rand.jl:5-13; RandomNumbers.jl) -----
+struct Rng { uint64_t x, y; };
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
+__device__ __forceinline__ uint64_t rng_next(Rng &r) {
+    uint64_t x = r.x, y = r.y;
+    uint64_t out = x + y;
+    uint64_t s1 = x ^ y;
+    r.x = rotl64(x, 55) ^ s1 ^ (s1 << 14);
+    r.y = rotl64(s1, 36);
+    return out;
+}
+__device__ __forceinline__ uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+// the independent stream of (render seed, pixel, sample chunk) -- DESIGN.md section 5
+__device__ __forceinline__ void rng_stream(uint64_t seed, uint64_t pixel, uint64_t chunk, Rng &r) {
+    uint64_t s = seed ^ (0xd1b54a32d192ed03ULL * (pixel + 1)) ^ (0x8cb92ba72f3d8dd7ULL * (chunk + 1));
+    r.x = splitmix64(s);
+    r.y = splitmix64(s);
+    (void)rng_next(r);
+}
+// rand(rng, Float32): low 23 bits -> [1,2) - 1;  rand(rng, Float64): low 52 bits -> [1,2) - 1
+__device__ __forceinline__ void trand(Rng &r, float &out) {
+    uint32_t bits = ((uint32_t)rng_next(r) & 0x007fffffu) | 0x3f800000u;
+    out = __uint_as_float(bits) - 1.0f;
+}
+__device__ __forceinline__ void trand(Rng &r, double &out) {
+    uint64_t bits = (rng_next(r) & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    out = __longlong_as_double((long long)bits) - 1.0;
+}
+// src/rand.jl:24  trand(T)*(max-min) + min
+template <typename T> __device__ __forceinline__ T random_between(Rng &r, T mn, T mx) {
+    T u; trand(r, u);
+    return u * (mx - mn) + mn;
+}
+// src/rand.jl:15-22,29: rejection in the unit ball (x,y,z order, boundary inclusive), normalised
+template <typename T> __device__ __forceinline__ V3<T> random_vec3_on_sphere(Rng &r) {
+    V3<T> p;
+    for (;;) {
+        p.x = random_between(r, T(-1), T(1));
+        p.y = random_between(r, T(-1), T(1));
+        p.z = random_between(r, T(-1), T(1));
+        if (dot(p, p) <= T(1)) break;
+    }
+    return normalize(p);
+}
+// src/rand.jl:31-38
+template <typename T> __device__ __forceinline__ void random_vec2_in_disk(Rng &r, T &x, T &y) {
+    for (;;) {
+        x = random_between(r, T(-1), T(1));
+        y = random_between(r, T(-1), T(1));
+        if (x * x + y * y <= T(1)) break;
+    }
+}
+
+// ---- intersection (src/hit.jl) ---------------------------------------------------------------
+// The per-sphere test of src/hit.jl:13-18 in the contracted form of the numerics contract.
+// r2 = r*r is precomputed at upload (same bits as computing it here).
+template <typename T>
+__device__ __forceinline__ void sphere_disc(T cx, T cy, T cz, T r2, V3<T> o, V3<T> d, T &half_b, T &disc) {
+    T ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
+    half_b = t_fma(ocz, d.z, t_fma(ocy, d.y, ocx * d.x));
+    T nc = t_fma(-ocz, ocz, t_fma(-ocy, ocy, t_fma(-ocx, ocx, r2)));
+    disc = t_fma(half_b, half_b, nc);
+}
+// src/hit.jl:19-29: root selection against [tmin, closest]; returns true and the root on a hit
+template <typename T>
+__device__ __forceinline__ bool sphere_root(T half_b, T disc, T tmin, T closest, T &root) {
+    if (disc < T(0)) return false;
+    T sqrtd = t_sqrt(disc);
+    root = -half_b - sqrtd;
+    if (root < tmin || closest < root) {
+        root = -half_b + sqrtd;
+        if (root < tmin || closest < root) return false;
+    }
+    return true;
+}
+
+template <typename T> struct HitRec { T t; V3<T> p, n; bool front; };
+
+// src/hit.jl:31-34 + ray_to_HitRecord :6-10 + point :3, for the sphere that won the scan
+template <typename T>
+__device__ __forceinline__ void make_hitrec(V3<T> c, T r, V3<T> o, V3<T> d, T t, HitRec<T> &rec) {
+    rec.t = t;
+    rec.p = vadd(o, vscale(t, d));
+    V3<T> pc = vsub(rec.p, c);
+    V3<T> n_out = {pc.x / r, pc.y / r, pc.z / r};
+    rec.front = dot(d, n_out) < T(0);
+    rec.n = rec.front ? n_out : vneg(n_out);
+}
+
+// ---- light transport (src/light.jl) ----------------------------------------------------------
+template <typename T> __device__ __forceinline__ V3<T> reflect(V3<T> v, V3<T> n) {   // :6
+    T k = dot(vscale(T(2), v), n);
+    return vsub(v, vscale(k, n));
+}
+template <typename T> __device__ __forceinline__ V3<T> refract(V3<T> dir, V3<T> n, T ratio) {  // :12-17
+    T cos_t = -dot(dir, n);
+    if (!(T(1) > cos_t)) cos_t = T(1);
+    V3<T> perp = vscale(ratio, vadd(dir, vscale(cos_t, n)));
+    T one_m = T(1) - dot(perp, perp);
+    T par_s = -t_sqrt(one_m < T(0) ? -one_m : one_m);
+    return normalize(vadd(perp, vscale(par_s, n)));
+}
+template <typename T> __device__ __forceinline__ T reflectance(T cos_t, T ratio) {   // :19-25
+    T r0 = (T(1) - ratio) / (T(1) + ratio);
+    r0 = r0 * r0;
+    T x = T(1) - cos_t;
+    T x2 = x * x;
+    T x5 = (x2 * x2) * x;
+    return r0 + (T(1) - r0) * x5;
+}
+
+// ---- materials (src/material.jl:13-53) -------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void scatter(Rng &rng, int kind, V3<T> albedo, T param, V3<T> d_in,
+                                        const HitRec<T> &rec, V3<T> &out_d, V3<T> &att) {
+    if (kind == DIELECTRIC) {                                     // :41-53
+        att = {T(1), T(1), T(1)};
+        T ratio = rec.front ? (T(1) / param) : param;
+        T cos_t = -dot(d_in, rec.n);
+        if (!(T(1) > cos_t)) cos_t = T(1);
+        T sin_t = t_sqrt(T(1) - cos_t * cos_t);
+        bool refl = ratio * sin_t > T(1);
+        if (!refl) {                                              // :47 short-circuit draw
+            T u; trand(rng, u);
+            refl = reflectance(cos_t, ratio) > u;
+        }
+        out_d = refl ? reflect(d_in, rec.n) : refract(d_in, rec.n, ratio);
+    } else {
+        // Lambertian (:13-23) and Metal (:31-34) both start from one random unit vector
+        V3<T> uvec = random_vec3_on_sphere<T>(rng);
+        att = albedo;
+        if (kind == LAMBERTIAN) {
+            V3<T> dir = vadd(rec.n, uvec);
+            out_d = near_zero(dir) ? rec.n : normalize(dir);
+        } else {
+            V3<T> refl = reflect(d_in, rec.n);
+            out_d = normalize(vadd(refl, vscale(param, uvec)));
+        }
+    }
+}
+
+// ---- sky (src/ray_color.jl:1-6): Float64 constants ------------------------------------------
+template <typename T> __device__ __forceinline__ C3 skycolor(V3<T> d) {
+    T t = T(0.5) * (d.y + T(1));
+    T omt = T(1) - t;
+    return {(double)omt * 1.0 + (double)t * 0.5, (double)omt * 1.0 + (double)t * 0.7,
+            (double)omt * 1.0 + (double)t * 1.0};
+}
+
+// ---- camera (src/camera.jl:43-48) ------------------------------------------------------------
+template <typename T> struct Camera {
+    T origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    T lens_radius;
+};
+template <typename T>
+__device__ __forceinline__ void get_ray(Rng &rng, const Camera<T> &cam, T s, T t, V3<T> &ro, V3<T> &rd) {
+    T dx, dy;
+    random_vec2_in_disk(rng, dx, dy);
+    T rx = cam.lens_radius * dx, ry = cam.lens_radius * dy;
+    V3<T> cu = {cam.u[0], cam.u[1], cam.u[2]}, cv = {cam.v[0], cam.v[1], cam.v[2]};
+    V3<T> org = {cam.origin[0], cam.origin[1], cam.origin[2]};
+    V3<T> llc = {cam.llc[0], cam.llc[1], cam.llc[2]};
+    V3<T> hor = {cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]};
+    V3<T> ver = {cam.vertical[0], cam.vertical[1], cam.vertical[2]};
+    V3<T> offset = vadd(vscale(rx, cu), vscale(ry, cv));
+    ro = vadd(org, offset);
+    V3<T> dir = vadd(llc, vscale(s, hor));
+    dir = vadd(dir, vscale(t, ver));
+    dir = vsub(dir, org);
+    dir = vsub(dir, offset);
+    rd = normalize(dir);
+}
+
+// ---- device scene ----------------------------------------------------------------------------
+// geom[i] = (cx, cy, cz, r*r)   hot: 16 B (f32) / 32 B (f64) per sphere, wave-uniform reads
+// mat0[i] = (r, param, kind, 0) cold: read once per segment by the lane that hit sphere i
+// mat1[i] = (ar, ag, ab, 0)
+// geom is padded to a multiple of RTW_SPHERE_PAD with spheres that can never be hit (r2 < 0).
+#define RTW_SPHERE_PAD 16
+template <typename T> struct DevScene {
+    const typename Vec4<T>::type *geom;
+    const typename Vec4<T>::type *mat0;
+    const typename Vec4<T>::type *mat1;
+    int n, n_pad;
+};
+
+// src/hit.jl:38-50: closest hit by linear scan; `closest` shrinks; later sphere wins exact ties.
+template <typename T>
+__device__ __forceinline__ int hit_world(const DevScene<T> &w, V3<T> o, V3<T> d, T tmin, T tmax, T &t_hit) {
+    T closest = tmax;
+    int idx = -1;
+    for (int i = 0; i < w.n_pad; ++i) {
+        typename Vec4<T>::type s = w.geom[i];
+        T hb, disc, root;
+        sphere_disc<T>(s.x, s.y, s.z, s.w, o, d, hb, disc);
+        if (sphere_root<T>(hb, disc, tmin, closest, root)) { closest = root; idx = i; }
+    }
+    t_hit = closest;
+    return idx;
+}
+
+}  // namespace rtw

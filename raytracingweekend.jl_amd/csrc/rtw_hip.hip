@@ -1,0 +1,390 @@
+// rtw_hip.hip -- C ABI of librtw_hip.so (include/rtw_hip.h) over the gfx950 kernels.
+// Replaces /root/reference/src/render.jl:8-44 behind a ccall-able boundary.  No CPU fallback:
+// every compute entry point needs a HIP device and reports an error otherwise.
+#include "../../include/rtw_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "rtw_kernels.hpp"
+#include "rtw_units.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- per-device context: cached workspace, counters, events ---------------------------------
+struct DeviceCtx {
+    int device = -1;
+    double *partial = nullptr;
+    size_t partial_bytes = 0;
+    rtw::DevCounters *ctr = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    int num_cus = 0;
+    // last render
+    bool pending = false;
+    uint64_t last_samples_expected = 0;
+    int last_n = 0, last_chunks = 0, last_grid = 0, last_block = 0;
+};
+
+std::mutex g_mu;
+std::vector<DeviceCtx *> g_ctx;
+thread_local DeviceCtx *g_last = nullptr;
+
+int get_ctx(int device, DeviceCtx **out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (DeviceCtx *c : g_ctx)
+        if (c->device == device) { *out = c; return 0; }
+    DeviceCtx *c = new DeviceCtx();
+    c->device = device;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(-20, "device %d is %s; librtw_hip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    c->num_cus = prop.multiProcessorCount;
+    HIP_TRY(hipMalloc(&c->ctr, sizeof(rtw::DevCounters)));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipEventCreate(&c->ev2));
+    g_ctx.push_back(c);
+    *out = c;
+    return 0;
+}
+
+int resolve_device(int device, int *out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(e != hipSuccess ? (int)e : -21, "no HIP device available (%s); librtw_hip has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0) { HIP_TRY(hipGetDevice(&device)); }
+    if (device >= n) return fail(-22, "device %d out of range (%d devices)", device, n);
+    *out = device;
+    return 0;
+}
+
+}  // namespace
+
+// ---- device scene handle ---------------------------------------------------------------------
+struct rtw_scene_dev {
+    int device;
+    int is_f64;
+    int n, n_pad;
+    void *geom, *mat0, *mat1;
+};
+
+namespace {
+
+template <typename T, typename SceneT>
+int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
+    if (!s || !out) return fail(-1, "null argument");
+    if (s->n < 0) return fail(-2, "scene.n < 0");
+    if (s->n > 0 && (!s->cx || !s->cy || !s->cz || !s->r || !s->kind || !s->ar || !s->ag || !s->ab || !s->param))
+        return fail(-1, "null scene array");
+    for (int i = 0; i < s->n; ++i) {
+        if (s->kind[i] < 0 || s->kind[i] > 2) return fail(-3, "sphere %d: unknown material kind %d", i, s->kind[i]);
+    }
+    int dev;
+    if (int rc = resolve_device(device, &dev)) return rc;
+    DeviceCtx *ctx;
+    if (int rc = get_ctx(dev, &ctx)) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    using V4 = typename rtw::Vec4<T>::type;
+    const int n = s->n;
+    const int n_pad = ((n + RTW_SPHERE_PAD - 1) / RTW_SPHERE_PAD) * RTW_SPHERE_PAD + (n == 0 ? RTW_SPHERE_PAD : 0);
+    std::vector<V4> geom(n_pad), mat0(n_pad), mat1(n_pad);
+    for (int i = 0; i < n_pad; ++i) {
+        if (i < n) {
+            geom[i] = V4{s->cx[i], s->cy[i], s->cz[i], s->r[i] * s->r[i]};  // r^2: src/hit.jl:17
+            mat0[i] = V4{s->r[i], s->param[i], (T)s->kind[i], (T)0};
+            mat1[i] = V4{s->ar[i], s->ag[i], s->ab[i], (T)0};
+        } else {
+            // padding sphere that can never be hit: r^2 hugely negative => disc < 0 always
+            geom[i] = V4{(T)0, (T)0, (T)0, (T)-1e30};
+            mat0[i] = V4{(T)1, (T)0, (T)0, (T)0};
+            mat1[i] = V4{(T)0, (T)0, (T)0, (T)0};
+        }
+    }
+    rtw_scene_dev *h = new rtw_scene_dev();
+    h->device = dev; h->is_f64 = sizeof(T) == 8; h->n = n; h->n_pad = n_pad;
+    h->geom = h->mat0 = h->mat1 = nullptr;
+    const size_t bytes = sizeof(V4) * (size_t)n_pad;
+    HIP_TRY(hipMalloc(&h->geom, bytes));
+    HIP_TRY(hipMalloc(&h->mat0, bytes));
+    HIP_TRY(hipMalloc(&h->mat1, bytes));
+    HIP_TRY(hipMemcpy(h->geom, geom.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->mat0, mat0.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->mat1, mat1.data(), bytes, hipMemcpyHostToDevice));
+    *out = h;
+    return 0;
+}
+
+int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
+    if (!p) return fail(-1, "null params");
+    if (p->width <= 0 || p->height <= 0) return fail(-2, "width/height must be positive (got %d x %d)", p->width, p->height);
+    if (p->spp <= 0) return fail(-2, "spp must be positive (got %d)", p->spp);
+    if (p->max_depth < 0) return fail(-2, "max_depth must be >= 0");
+    if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
+        return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
+    if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
+    if (p->flags != 0) return fail(-2, "flags must be 0");
+    int nch = p->n_chunks > 0 ? p->n_chunks : (p->spp < 16 ? p->spp : 16);
+    if (nch > p->spp) nch = p->spp;
+    int cs = (p->spp + nch - 1) / nch;
+    *chunk_spp = cs;
+    *n_chunks = (p->spp + cs - 1) / cs;
+    return 0;
+}
+
+template <typename T, typename CamT>
+int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, void *d_out, void *stream_v) {
+    if (!scene || !cam || !d_out) return fail(-1, "null argument");
+    if (scene->is_f64 != (sizeof(T) == 8)) return fail(-4, "scene handle precision does not match the call");
+    int nch, cs;
+    if (int rc = validate_params(p, &nch, &cs)) return rc;
+    if (p->device >= 0 && p->device != scene->device)
+        return fail(-4, "params.device %d != scene device %d", p->device, scene->device);
+    DeviceCtx *ctx;
+    if (int rc = get_ctx(scene->device, &ctx)) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t stream = (hipStream_t)stream_v;
+
+    rtw::KParams K;
+    K.width = p->width; K.height = p->height; K.spp = p->spp; K.max_depth = p->max_depth;
+    K.seed = p->seed; K.n_chunks = nch; K.chunk_spp = cs;
+    K.shard_index = p->shard_index; K.shard_count = p->shard_count;
+    K.tiles_i = (p->height + 7) / 8; K.tiles_j = (p->width + 7) / 8;
+    const long long n_tiles = (long long)K.tiles_i * K.tiles_j;
+    const long long n_local = n_tiles > p->shard_index ? (n_tiles - p->shard_index + p->shard_count - 1) / p->shard_count : 0;
+    const long long total_items = n_local * nch * 64;
+    if (total_items >= (1ll << 31)) return fail(-5, "render too large for one call: %lld work items", total_items);
+    K.n_local_tiles = (int)n_local; K.total_items = (unsigned)total_items; K.gamma = p->gamma;
+
+    const size_t need = (size_t)(total_items > 0 ? total_items : 1) * 3 * sizeof(double);
+    if (ctx->partial_bytes < need) {
+        if (ctx->partial) { HIP_TRY(hipFree(ctx->partial)); ctx->partial = nullptr; ctx->partial_bytes = 0; }
+        HIP_TRY(hipMalloc(&ctx->partial, need));
+        ctx->partial_bytes = need;
+    }
+
+    rtw::Camera<T> C;
+    for (int k = 0; k < 3; ++k) {
+        C.origin[k] = cam->origin[k]; C.llc[k] = cam->lower_left_corner[k];
+        C.horizontal[k] = cam->horizontal[k]; C.vertical[k] = cam->vertical[k];
+        C.u[k] = cam->u[k]; C.v[k] = cam->v[k]; C.w[k] = cam->w[k];
+    }
+    C.lens_radius = cam->lens_radius;
+    rtw::DevScene<T> S;
+    using V4 = typename rtw::Vec4<T>::type;
+    S.geom = (const V4 *)scene->geom; S.mat0 = (const V4 *)scene->mat0; S.mat1 = (const V4 *)scene->mat1;
+    S.n = scene->n; S.n_pad = scene->n_pad;
+
+    // persistent grid: enough 256-thread blocks to fill every CU at the kernel's occupancy
+    int blocks_per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, rtw::trace_kernel<T>, 256, 0));
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    long long grid = (long long)ctx->num_cus * blocks_per_cu;
+    const long long max_useful = (total_items + 255) / 256;
+    if (grid > max_useful) grid = max_useful;
+    if (grid < 1) grid = 1;
+
+    HIP_TRY(hipMemsetAsync(ctx->ctr, 0, sizeof(rtw::DevCounters), stream));
+    HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)p->width * p->height * 3 * sizeof(T), stream));
+    HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    hipLaunchKernelGGL(rtw::trace_kernel<T>, dim3((unsigned)grid), dim3(256), 0, stream, K, C, S, ctx->partial, ctx->ctr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev1, stream));
+    const unsigned n_pix_local = (unsigned)n_local * 64u;
+    if (n_pix_local > 0) {
+        hipLaunchKernelGGL(rtw::finalize_kernel<T>, dim3((n_pix_local + 255) / 256), dim3(256), 0, stream, K,
+                           (const double *)ctx->partial, (T *)d_out);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ctx->ev2, stream));
+    ctx->pending = true;
+    ctx->last_n = scene->n; ctx->last_chunks = nch; ctx->last_grid = (int)grid; ctx->last_block = 256;
+    g_last = ctx;
+    return 0;
+}
+
+template <typename T, typename SceneT, typename CamT>
+int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *out) {
+    if (!scene || !cam || !p || !out) return fail(-1, "null argument");
+    rtw_scene_handle h = nullptr;
+    int rc = upload_scene<T>(scene, p->device, &h);
+    if (rc) return rc;
+    void *d_out = nullptr;
+    const size_t bytes = (size_t)p->width * (size_t)p->height * 3 * sizeof(T);
+    hipError_t e = (p->width > 0 && p->height > 0) ? hipMalloc(&d_out, bytes) : hipSuccess;
+    if (e != hipSuccess) { rtw_scene_free(h); return fail((int)e, "hipMalloc(image) failed: %s", hipGetErrorString(e)); }
+    rc = d_out ? render_device<T>(h, cam, p, d_out, nullptr) : fail(-2, "width/height must be positive");
+    if (!rc) {
+        e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);   // blocking: waits for the render
+        if (e != hipSuccess) rc = fail((int)e, "hipMemcpy(image D2H) failed: %s", hipGetErrorString(e));
+    }
+    if (d_out) hipFree(d_out);
+    rtw_scene_free(h);
+    return rc;
+}
+
+// T0 unit entry point: host slots -> device -> unit_kernel -> host slots
+template <typename T, typename SceneT, typename CamT>
+int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, const CamT *cam) {
+    if (op < 0 || op >= rtw::U_NUM_OPS) return fail(-2, "unknown unit op %d", op);
+    if (count < 0 || (count > 0 && (!in || !out))) return fail(-1, "null argument");
+    if (count == 0) return 0;
+    const bool needs_scene = op == rtw::U_HIT_WORLD || op == rtw::U_RAY_COLOR;
+    if (needs_scene && !scene) return fail(-1, "op %d needs a scene", op);
+    if (op == rtw::U_GET_RAY && !cam) return fail(-1, "op %d needs a camera", op);
+    int dev;
+    if (int rc = resolve_device(-1, &dev)) return rc;
+    DeviceCtx *ctx;
+    if (int rc = get_ctx(dev, &ctx)) return rc;
+    rtw_scene_handle h = nullptr;
+    rtw::DevScene<T> S{nullptr, nullptr, nullptr, 0, 0};
+    if (needs_scene) {
+        if (int rc = upload_scene<T>(scene, dev, &h)) return rc;
+        using V4 = typename rtw::Vec4<T>::type;
+        S.geom = (const V4 *)h->geom; S.mat0 = (const V4 *)h->mat0; S.mat1 = (const V4 *)h->mat1;
+        S.n = h->n; S.n_pad = h->n_pad;
+    }
+    rtw::Camera<T> C;
+    memset(&C, 0, sizeof C);
+    if (cam) {
+        for (int k = 0; k < 3; ++k) {
+            C.origin[k] = cam->origin[k]; C.llc[k] = cam->lower_left_corner[k];
+            C.horizontal[k] = cam->horizontal[k]; C.vertical[k] = cam->vertical[k];
+            C.u[k] = cam->u[k]; C.v[k] = cam->v[k]; C.w[k] = cam->w[k];
+        }
+        C.lens_radius = cam->lens_radius;
+    }
+    const size_t in_b = (size_t)count * rtw::unit_in_slots(op) * 8, out_b = (size_t)count * rtw::unit_out_slots(op) * 8;
+    double *d_in = nullptr, *d_out = nullptr;
+    int rc = 0;
+    hipError_t e;
+    if ((e = hipMalloc(&d_in, in_b)) != hipSuccess || (e = hipMalloc(&d_out, out_b)) != hipSuccess ||
+        (e = hipMemcpy(d_in, in, in_b, hipMemcpyHostToDevice)) != hipSuccess) {
+        rc = fail((int)e, "unit buffers: %s", hipGetErrorString(e));
+    } else {
+        hipLaunchKernelGGL(rtw::unit_kernel<T>, dim3((count + 63) / 64), dim3(64), 0, 0, op, count, d_in, d_out, S, C);
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost)) != hipSuccess)
+            rc = fail((int)e, "unit kernel: %s", hipGetErrorString(e));
+    }
+    if (d_in) hipFree(d_in);
+    if (d_out) hipFree(d_out);
+    if (h) rtw_scene_free(h);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtw_abi_version(void) { return RTW_ABI_VERSION; }
+
+int rtw_device_count(int *count) {
+    if (!count) return fail(-1, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail((int)e, "hipGetDeviceCount failed: %s", hipGetErrorString(e)); }
+    *count = n;
+    return 0;
+}
+
+const char *rtw_last_error(void) { return g_err; }
+
+int rtw_scene_upload_f32(const rtw_scene_f32 *s, int device, rtw_scene_handle *out) { return upload_scene<float>(s, device, out); }
+int rtw_scene_upload_f64(const rtw_scene_f64 *s, int device, rtw_scene_handle *out) { return upload_scene<double>(s, device, out); }
+
+int rtw_scene_free(rtw_scene_handle h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    if (h->geom) hipFree(h->geom);
+    if (h->mat0) hipFree(h->mat0);
+    if (h->mat1) hipFree(h->mat1);
+    delete h;
+    return 0;
+}
+
+int rtw_render_device_f32(rtw_scene_handle s, const rtw_camera_f32 *c, const rtw_params *p, void *d_out, void *stream) {
+    return render_device<float>(s, c, p, d_out, stream);
+}
+int rtw_render_device_f64(rtw_scene_handle s, const rtw_camera_f64 *c, const rtw_params *p, void *d_out, void *stream) {
+    return render_device<double>(s, c, p, d_out, stream);
+}
+int rtw_render_f32(const rtw_scene_f32 *s, const rtw_camera_f32 *c, const rtw_params *p, float *out) {
+    return render_host<float>(s, c, p, out);
+}
+int rtw_render_f64(const rtw_scene_f64 *s, const rtw_camera_f64 *c, const rtw_params *p, double *out) {
+    return render_host<double>(s, c, p, out);
+}
+
+int rtw_stats(rtw_stats_t *out) {
+    if (!out) return fail(-1, "null argument");
+    DeviceCtx *ctx = g_last;
+    if (!ctx) return fail(-6, "no render has been issued from this thread");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->ev2));
+    float k_ms = 0, t_ms = 0;
+    HIP_TRY(hipEventElapsedTime(&k_ms, ctx->ev0, ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(&t_ms, ctx->ev0, ctx->ev2));
+    rtw::DevCounters c;
+    HIP_TRY(hipMemcpy(&c, ctx->ctr, sizeof c, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->samples = c.samples;
+    out->segments = c.segments;
+    out->sphere_tests = c.segments * (uint64_t)ctx->last_n;
+    out->kernel_ms = k_ms;
+    out->total_ms = t_ms;
+    out->n_chunks = ctx->last_chunks;
+    out->grid_blocks = ctx->last_grid;
+    out->block_threads = ctx->last_block;
+    return 0;
+}
+
+int rtw_unit_f32(int op, int count, const void *in, void *out, const rtw_scene_f32 *scene, const rtw_camera_f32 *cam) {
+    return run_unit<float>(op, count, in, out, scene, cam);
+}
+int rtw_unit_f64(int op, int count, const void *in, void *out, const rtw_scene_f64 *scene, const rtw_camera_f64 *cam) {
+    return run_unit<double>(op, count, in, out, scene, cam);
+}
+
+int rtw_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (DeviceCtx *c : g_ctx) {
+        hipSetDevice(c->device);
+        if (c->partial) hipFree(c->partial);
+        if (c->ctr) hipFree(c->ctr);
+        if (c->ev0) hipEventDestroy(c->ev0);
+        if (c->ev1) hipEventDestroy(c->ev1);
+        if (c->ev2) hipEventDestroy(c->ev2);
+        delete c;
+    }
+    g_ctx.clear();
+    g_last = nullptr;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+// rtw_kernels.hpp -- the trace kernel (render -> ray_color -> hit/scatter fused) and the
+// finalize kernel.  gfx950 only; wave = 64 lanes.
+//
+// Work decomposition
+//   item  = (pixel, sample chunk): `chunk_spp` consecutive samples of one pixel drawn from the
+//           item's own Xoroshiro128+ stream.  Items are enumerated tile-major: 64 consecutive
+//           items are one 8x8 pixel tile for one chunk, so a wave starts out coherent.
+//   lane  = persistent worker.  It owns one item at a time, regenerates a camera ray the moment
+//           its path ends (no lock-step with the other lanes' path lengths), and pulls the next
+//           item from a global queue when its chunk is finished.  The only convergent part is
+//           the sphere scan, which every live lane executes every iteration.
+//   out   = per-item chunk sums (3 doubles) -> finalize kernel adds them in chunk order, divides
+//           by spp, applies gamma and stores RGB{T}.  Results do not depend on scheduling, grid
+//           size or shard count.
+#pragma once
+#include "rtw_device.hpp"
+
+namespace rtw {
+
+struct KParams {
+    int width, height, spp, max_depth;
+    uint64_t seed;
+    int n_chunks;      // effective (non-empty) chunks per pixel
+    int chunk_spp;
+    int shard_index, shard_count;
+    int tiles_i, tiles_j;  // 8x8 tiles along rows (i) and columns (j)
+    int n_local_tiles;
+    unsigned total_items;  // n_local_tiles * n_chunks * 64
+    int gamma;
+};
+
+struct DevCounters {
+    unsigned long long next_item;
+    unsigned long long segments;
+    unsigned long long samples;
+};
+
+__device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,
+                                                   double *__restrict__ partial, DevCounters *ctr) {
+    const unsigned lane = lane_id();
+
+    // ---- per-lane state ----
+    bool alive = true;        // still pulling work
+    bool have_item = false;   // owns an item whose chunk sum is not yet flushed
+    bool has_ray = false;     // a path is in flight
+    unsigned item_slot = 0;   // where the chunk sum goes: (local pixel)*n_chunks + chunk
+    int samples_left = 0;
+    int s_global = 0;         // 0-based sample index within the pixel (sample 0 is un-jittered)
+    T pu = 0, pv = 0;         // pixel's (u, v)  (src/render.jl:26-27)
+    Rng rng = {1, 2};
+    double acc_r = 0, acc_g = 0, acc_b = 0;
+    V3<T> ro = {0, 0, 0}, rd = {0, 0, 1};
+    double thr_r = 1, thr_g = 1, thr_b = 1;
+    int depth_left = 0;
+    unsigned my_segments = 0, my_samples = 0;
+
+    const T inv_w_div = (T)(float)P.width;   // f32_image_width  (src/render.jl:16)
+    const T inv_h_div = (T)(float)P.height;  // f32_image_height (src/render.jl:17)
+
+    for (;;) {
+        // ---- (A) lanes whose chunk is done flush it and pull the next item ----
+        const bool need = alive && !has_ray && samples_left == 0;
+        const unsigned long long need_mask = __ballot(need);
+        if (need_mask) {
+            const unsigned cnt = __popcll(need_mask);
+            const unsigned leader = __ffsll((long long)need_mask) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&ctr->next_item, (unsigned long long)cnt);
+            base = __shfl(base, leader);
+            if (need) {
+                if (have_item) {
+                    double *dst = partial + (size_t)item_slot * 3;
+                    dst[0] = acc_r; dst[1] = acc_g; dst[2] = acc_b;
+                    have_item = false;
+                }
+                const unsigned rank = __popcll(need_mask & ((1ull << lane) - 1ull));
+                const unsigned long long idx = base + rank;
+                if (idx >= P.total_items) {
+                    alive = false;
+                } else {
+                    const unsigned per_tile = (unsigned)P.n_chunks * 64u;
+                    const unsigned k = (unsigned)idx / per_tile;         // local tile
+                    const unsigned rem = (unsigned)idx % per_tile;
+                    const unsigned chunk = rem >> 6, pl = rem & 63u;
+                    const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
+                    const int ti = (int)(t % (unsigned)P.tiles_i), tj = (int)(t / (unsigned)P.tiles_i);
+                    const int i0 = ti * 8 + (int)(pl & 7u), j0 = tj * 8 + (int)(pl >> 3);  // 0-based
+                    if (i0 < P.height && j0 < P.width) {
+                        const int i = i0 + 1, j = j0 + 1;                // Julia's 1-based (i, j)
+                        pu = (T)((double)j / (double)P.width);           // src/render.jl:26
+                        pv = (T)((double)(P.height - i) / (double)P.height);  // :27
+                        const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
+                        rng_stream(P.seed, pix, chunk, rng);
+                        s_global = (int)chunk * P.chunk_spp;
+                        const int s_end = min(P.spp, s_global + P.chunk_spp);
+                        samples_left = s_end - s_global;
+                        item_slot = (k * 64u + pl) * (unsigned)P.n_chunks + chunk;
+                        acc_r = acc_g = acc_b = 0.0;
+                        have_item = true;
+                    }
+                    // out-of-image pixel of an edge tile: nothing to do, pull again next round
+                }
+            }
+        }
+        if (!__any(alive)) break;
+
+        // ---- (B) start the next sample (src/render.jl:29-37) ----
+        if (alive && !has_ray && samples_left > 0) {
+            T du = 0, dv = 0;
+            if (s_global != 0) {
+                T r1, r2;
+                trand(rng, r1); du = r1 / inv_w_div;
+                trand(rng, r2); dv = r2 / inv_h_div;
+            }
+            get_ray(rng, cam, pu + du, pv + dv, ro, rd);
+            thr_r = thr_g = thr_b = 1.0;
+            depth_left = P.max_depth;
+            has_ray = depth_left > 0;    // depth <= 0: ray_color returns 0 (src/ray_color.jl:15)
+            samples_left -= 1;
+            s_global += 1;
+            my_samples += 1;
+        }
+
+        // ---- (C) closest hit over the whole sphere list (src/hit.jl:38-50) ----
+        T t_hit = 0;
+        int idx = -1;
+        if (has_ray) {
+            idx = hit_world(scene, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit);
+            my_segments += 1;
+        }
+
+        // ---- (D) shade (src/ray_color.jl:20-37) ----
+        if (has_ray) {
+            if (idx < 0) {
+                const C3 sky = skycolor(rd);
+                acc_r += thr_r * sky.r; acc_g += thr_g * sky.g; acc_b += thr_b * sky.b;
+                has_ray = false;
+            } else {
+                const typename Vec4<T>::type g = scene.geom[idx];
+                const typename Vec4<T>::type m0 = scene.mat0[idx];
+                const typename Vec4<T>::type m1 = scene.mat1[idx];
+                HitRec<T> rec;
+                make_hitrec<T>({g.x, g.y, g.z}, m0.x, ro, rd, t_hit, rec);
+                V3<T> nd, att;
+                scatter<T>(rng, (int)m0.z, {m1.x, m1.y, m1.z}, m0.y, rd, rec, nd, att);
+                thr_r = thr_r * (double)att.x; thr_g = thr_g * (double)att.y; thr_b = thr_b * (double)att.z;
+                ro = rec.p; rd = nd;
+                depth_left -= 1;
+                if (depth_left <= 0) has_ray = false;   // recursion bottoms out with 0 radiance
+            }
+        }
+    }
+
+    // counters (one atomic per lane at the very end; the compiler reduces them per wave)
+    atomicAdd(&ctr->segments, (unsigned long long)my_segments);
+    atomicAdd(&ctr->samples, (unsigned long long)my_samples);
+}
+
+// One thread per local pixel: chunk sums added in chunk order, / spp, gamma, store RGB{T}
+// (src/render.jl:40, src/vec.jl:22).  Column-major H x W, as Matrix{RGB{T}}.
+template <typename T>
+__global__ __launch_bounds__(256) void finalize_kernel(KParams P, const double *__restrict__ partial,
+                                                      T *__restrict__ out) {
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned n_local = (unsigned)P.n_local_tiles * 64u;
+    if (gid >= n_local) return;
+    const unsigned k = gid >> 6, pl = gid & 63u;
+    const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
+    const int ti = (int)(t % (unsigned)P.tiles_i), tj = (int)(t / (unsigned)P.tiles_i);
+    const int i0 = ti * 8 + (int)(pl & 7u), j0 = tj * 8 + (int)(pl >> 3);
+    if (i0 >= P.height || j0 >= P.width) return;
+    const double *src = partial + (size_t)gid * (size_t)P.n_chunks * 3;
+    double r = 0.0, g = 0.0, b = 0.0;
+    for (int c = 0; c < P.n_chunks; ++c) { r += src[c * 3 + 0]; g += src[c * 3 + 1]; b += src[c * 3 + 2]; }
+    const double n = (double)P.spp;
+    r = r / n; g = g / n; b = b / n;
+    if (P.gamma) { r = __builtin_sqrt(r); g = __builtin_sqrt(g); b = __builtin_sqrt(b); }
+    T *dst = out + ((size_t)j0 * (size_t)P.height + (size_t)i0) * 3;
+    dst[0] = (T)r; dst[1] = (T)g; dst[2] = (T)b;
+}
+
+}  // namespace rtw

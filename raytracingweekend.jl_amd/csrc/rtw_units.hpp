@@ -1,0 +1,148 @@
+// rtw_units.hpp -- unit-level device entry points for the T0 parity tier: one lane evaluates
+// one reference function on one input, using exactly the device functions the trace kernel
+// uses.  All I/O is in 8-byte slots: doubles for real values (exact for binary32 inputs),
+// raw uint64 for RNG state words.  Slot layouts are documented in tests/test_gpu_units.py.
+#pragma once
+#include "rtw_device.hpp"
+
+namespace rtw {
+
+enum UnitOp {
+    U_HIT_SPHERE = 0, U_REFLECT = 1, U_REFRACT = 2, U_REFLECTANCE = 3, U_SCATTER = 4,
+    U_GET_RAY = 5, U_SKYCOLOR = 6, U_RNG = 7, U_HIT_WORLD = 8, U_RAY_COLOR = 9, U_NUM_OPS = 10
+};
+
+__host__ __device__ inline int unit_in_slots(int op) {
+    switch (op) {
+        case U_HIT_SPHERE: return 12;   // c[3], r, o[3], d[3], tmin, tmax
+        case U_REFLECT: return 6;       // v[3], n[3]
+        case U_REFRACT: return 7;       // d[3], n[3], ratio
+        case U_REFLECTANCE: return 2;   // cos, ratio
+        case U_SCATTER: return 18;      // state[2], kind, albedo[3], param, d[3], rec{t,p[3],n[3],front}
+        case U_GET_RAY: return 4;       // state[2], s, t
+        case U_SKYCOLOR: return 3;      // d[3]
+        case U_RNG: return 2;           // state[2]
+        case U_HIT_WORLD: return 8;     // o[3], d[3], tmin, tmax
+        case U_RAY_COLOR: return 9;     // state[2], o[3], d[3], depth
+    }
+    return 0;
+}
+__host__ __device__ inline int unit_out_slots(int op) {
+    switch (op) {
+        case U_HIT_SPHERE: return 9;    // hit, t, p[3], n[3], front
+        case U_REFLECT: return 3;
+        case U_REFRACT: return 3;
+        case U_REFLECTANCE: return 1;
+        case U_SCATTER: return 11;      // state[2], o[3], d[3], att[3]
+        case U_GET_RAY: return 8;       // state[2], o[3], d[3]
+        case U_SKYCOLOR: return 3;
+        case U_RNG: return 6;           // state[2], 4 uniforms
+        case U_HIT_WORLD: return 9;     // idx, t, p[3], n[3], front
+        case U_RAY_COLOR: return 6;     // state[2], colour[3], segments
+    }
+    return 0;
+}
+
+template <typename T>
+__device__ __forceinline__ V3<T> ld3(const double *p) { return {(T)p[0], (T)p[1], (T)p[2]}; }
+template <typename T>
+__device__ __forceinline__ void st3(double *p, V3<T> v) { p[0] = (double)v.x; p[1] = (double)v.y; p[2] = (double)v.z; }
+__device__ __forceinline__ uint64_t as_u64(double d) { return (uint64_t)__double_as_longlong(d); }
+__device__ __forceinline__ double as_f64(uint64_t u) { return __longlong_as_double((long long)u); }
+
+template <typename T>
+__global__ void unit_kernel(int op, int count, const double *__restrict__ in, double *__restrict__ out,
+                            DevScene<T> scene, Camera<T> cam) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count) return;
+    const double *x = in + (size_t)gid * unit_in_slots(op);
+    double *y = out + (size_t)gid * unit_out_slots(op);
+    switch (op) {
+        case U_HIT_SPHERE: {
+            V3<T> c = ld3<T>(x), o = ld3<T>(x + 4), d = ld3<T>(x + 7);
+            T r = (T)x[3], tmin = (T)x[10], tmax = (T)x[11];
+            T hb, disc, root;
+            sphere_disc<T>(c.x, c.y, c.z, r * r, o, d, hb, disc);
+            for (int k = 0; k < 9; ++k) y[k] = 0.0;
+            if (sphere_root<T>(hb, disc, tmin, tmax, root)) {
+                HitRec<T> rec;
+                make_hitrec<T>(c, r, o, d, root, rec);
+                y[0] = 1.0; y[1] = (double)rec.t; st3(y + 2, rec.p); st3(y + 5, rec.n); y[8] = rec.front ? 1.0 : 0.0;
+            }
+        } break;
+        case U_REFLECT: st3(y, reflect(ld3<T>(x), ld3<T>(x + 3))); break;
+        case U_REFRACT: st3(y, refract(ld3<T>(x), ld3<T>(x + 3), (T)x[6])); break;
+        case U_REFLECTANCE: y[0] = (double)reflectance((T)x[0], (T)x[1]); break;
+        case U_SCATTER: {
+            Rng rng = {as_u64(x[0]), as_u64(x[1])};
+            HitRec<T> rec;
+            rec.t = (T)x[10]; rec.p = ld3<T>(x + 11); rec.n = ld3<T>(x + 14); rec.front = x[17] != 0.0;
+            V3<T> nd, att;
+            scatter<T>(rng, (int)x[2], ld3<T>(x + 3), (T)x[6], ld3<T>(x + 7), rec, nd, att);
+            y[0] = as_f64(rng.x); y[1] = as_f64(rng.y);
+            st3(y + 2, rec.p); st3(y + 5, nd); st3(y + 8, att);
+        } break;
+        case U_GET_RAY: {
+            Rng rng = {as_u64(x[0]), as_u64(x[1])};
+            V3<T> o, d;
+            get_ray(rng, cam, (T)x[2], (T)x[3], o, d);
+            y[0] = as_f64(rng.x); y[1] = as_f64(rng.y);
+            st3(y + 2, o); st3(y + 5, d);
+        } break;
+        case U_SKYCOLOR: {
+            C3 c = skycolor(ld3<T>(x));
+            y[0] = c.r; y[1] = c.g; y[2] = c.b;
+        } break;
+        case U_RNG: {
+            Rng rng = {as_u64(x[0]), as_u64(x[1])};
+            for (int k = 0; k < 4; ++k) { T u; trand(rng, u); y[2 + k] = (double)u; }
+            y[0] = as_f64(rng.x); y[1] = as_f64(rng.y);
+        } break;
+        case U_HIT_WORLD: {
+            V3<T> o = ld3<T>(x), d = ld3<T>(x + 3);
+            T t_hit;
+            int idx = hit_world(scene, o, d, (T)x[6], (T)x[7], t_hit);
+            for (int k = 0; k < 9; ++k) y[k] = 0.0;
+            y[0] = (double)idx;
+            if (idx >= 0) {
+                auto g = scene.geom[idx];
+                auto m0 = scene.mat0[idx];
+                HitRec<T> rec;
+                make_hitrec<T>({g.x, g.y, g.z}, m0.x, o, d, t_hit, rec);
+                y[1] = (double)rec.t; st3(y + 2, rec.p); st3(y + 5, rec.n); y[8] = rec.front ? 1.0 : 0.0;
+            }
+        } break;
+        case U_RAY_COLOR: {
+            // src/ray_color.jl:14-38 as the iterative front-to-back loop of the trace kernel
+            Rng rng = {as_u64(x[0]), as_u64(x[1])};
+            V3<T> o = ld3<T>(x + 2), d = ld3<T>(x + 5);
+            int depth = (int)x[8];
+            double tr = 1, tg = 1, tb = 1, cr = 0, cg = 0, cb = 0;
+            unsigned segs = 0;
+            while (depth > 0) {
+                T t_hit;
+                int idx = hit_world(scene, o, d, (T)1e-4, (T)__builtin_huge_val(), t_hit);
+                segs++;
+                if (idx < 0) {
+                    C3 sky = skycolor(d);
+                    cr = tr * sky.r; cg = tg * sky.g; cb = tb * sky.b;
+                    break;
+                }
+                auto g = scene.geom[idx];
+                auto m0 = scene.mat0[idx];
+                auto m1 = scene.mat1[idx];
+                HitRec<T> rec;
+                make_hitrec<T>({g.x, g.y, g.z}, m0.x, o, d, t_hit, rec);
+                V3<T> nd, att;
+                scatter<T>(rng, (int)m0.z, {m1.x, m1.y, m1.z}, m0.y, d, rec, nd, att);
+                tr = tr * (double)att.x; tg = tg * (double)att.y; tb = tb * (double)att.z;
+                o = rec.p; d = nd;
+                depth -= 1;
+            }
+            y[0] = as_f64(rng.x); y[1] = as_f64(rng.y);
+            y[2] = cr; y[3] = cg; y[4] = cb; y[5] = (double)segs;
+        } break;
+    }
+}
+
+}  // namespace rtw

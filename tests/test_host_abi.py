@@ -1,0 +1,89 @@
+"""Host logic and the C-ABI boundary, CPU only: the library loads and exports every symbol
+include/rtw_hip.h declares; argument validation; no compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol(rtw):
+    from rtw_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    L = _capi.lib()
+    header = open(os.path.join(ROOT, "include", "rtw_hip.h")).read()
+    declared = set(re.findall(r"\b(rtw_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.rtw_abi_version() == 1
+
+
+def test_struct_layouts_match_header(rtw):
+    from rtw_amd import _capi
+    assert ctypes.sizeof(_capi.CameraF32) == 22 * 4 and ctypes.sizeof(_capi.CameraF64) == 22 * 8
+    assert ctypes.sizeof(_capi.Params) == 48 and _capi.Params.seed.offset == 16
+    assert ctypes.sizeof(_capi.Stats) == 56
+    assert ctypes.sizeof(_capi.SceneF32) == 80 and _capi.SceneF32.kind.offset == 40
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_render_fails_loudly_without_gpu(rtw):
+    """No CPU fallback: on a box without a HIP device render() raises instead of producing pixels."""
+    from rtw_amd._capi import RtwError
+    scene = rtw.scene_2_spheres(elem_type=np.float32)
+    with pytest.raises(RtwError, match="no HIP device|hip"):
+        rtw.render(scene, rtw.t_default_cam(), 96, 1)
+
+
+def test_render_argument_validation(rtw):
+    scene = rtw.scene_2_spheres(elem_type=np.float32)
+    cam = rtw.t_default_cam()
+    with pytest.raises(ValueError):
+        rtw.render(scene, cam, 0, 1)
+    with pytest.raises(ValueError):
+        rtw.render(scene, cam, 96, 0)
+    with pytest.raises(TypeError):
+        rtw.render(scene, "not a camera", 96, 1)
+    with pytest.raises(TypeError):
+        rtw.render(rtw.HittableList([object()]), cam, 96, 1)       # non-Sphere hittable
+    bad = rtw.HittableList([rtw.Sphere(np.zeros(3, np.float32), 1.0, object())])
+    with pytest.raises(TypeError):
+        rtw.render(bad, cam, 96, 1)
+
+
+def test_flatten_scene_layout(rtw):
+    s = rtw.scene_diel_spheres(-0.5, elem_type=np.float32)
+    f = rtw.flatten_scene(s, np.float32)
+    assert f["n"] == 4 and list(f["kind"]) == [0, 0, 2, 1]
+    assert f["r"][2] == np.float32(-0.5) and f["param"][2] == np.float32(1.5) and f["param"][3] == 0
+    assert all(f[k].dtype == np.float32 for k in ("cx", "cy", "cz", "r", "ar", "ag", "ab", "param"))
+    assert rtw.flatten_scene(rtw.HittableList(), np.float64)["n"] == 0
+
+
+def test_blue_red_scene_is_float64_only(rtw):
+    with pytest.raises(TypeError):
+        rtw.scene_blue_red_spheres(elem_type=np.float32)
+    assert len(rtw.scene_blue_red_spheres(elem_type=np.float64)) == 2
+
+
+def test_owned_pixel_mask_partition(rtw):
+    for width in (96, 100, 320):
+        for n in (1, 2, 3, 8):
+            masks = [rtw.owned_pixel_mask(width, r, n) for r in range(n)]
+            tot = np.sum(masks, axis=0)
+            assert np.all(tot == 1)                               # disjoint and complete
+            assert masks[0].shape == (rtw.image_height(width), width)

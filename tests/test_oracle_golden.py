@@ -1,0 +1,108 @@
+"""Oracle vs the committed golden vectors (tests/golden, made by tools/make_golden.py), oracle
+mode cross-checks, and the host mirror vs the oracle's mirror of the producers.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_reproduces_golden(oracle, name):
+    g = load_golden(name)
+    T = g["image"].dtype.type
+    img, st = oracle.render(g["flat"], g["cam"], g["width"], g["height"], g["spp"], T=T, max_depth=g["depth"],
+                            seed=g["seed"], n_chunks=g["n_chunks"], product_order=oracle.PRODUCT_FORWARD)
+    assert np.array_equal(img, g["image"])                    # bit-exact
+    assert st["segments"] == g["segments"] and st["rng_draws"] == g["rng_draws"]
+
+
+@pytest.mark.parametrize("name", [c for c in GOLDEN_CASES if "cfg2" not in c])
+def test_forward_product_matches_reference_order(name):
+    """The device multiplies attenuations front to back; the reference multiplies them as the
+    recursion unwinds (src/ray_color.jl:31).  In binary64 the two differ by rounding only:
+    for T = Float32 (colour math is binary64) the stored images agree to <= 1 ulp of Float32;
+    for T = Float64 the product chain itself is rounded in T, so allow a few dozen ulps."""
+    g = load_golden(name)
+    a, b = g["image"], g["image_reference_order"]
+    T = a.dtype.type
+    ulp = np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(T))
+    tol = 1 if T is np.float32 else 64
+    assert np.all(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= tol * ulp)
+    if T is np.float32:
+        assert (a != b).mean() < 1e-3
+
+
+def test_thread_count_invariance_pixel_stream(oracle):
+    g = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
+    kw = dict(T=np.float32, max_depth=g["depth"], seed=g["seed"], n_chunks=g["n_chunks"])
+    a, _ = oracle.render(g["flat"], g["cam"], g["width"], g["height"], g["spp"], omp_threads=1, **kw)
+    b, _ = oracle.render(g["flat"], g["cam"], g["width"], g["height"], g["spp"], omp_threads=4, **kw)
+    assert np.array_equal(a, b) and np.array_equal(a, g["image"])
+
+
+def test_ref_serial_mode_statistics(oracle):
+    """REF_SERIAL mirrors the reference's per-thread serial RNG (src/init.jl:7-10, src/rand.jl:2,
+    src/render.jl:21-23).  It is a different random sequence from PIXEL_STREAM, so images agree
+    statistically only (tier T3): per-channel mean within Monte-Carlo error."""
+    g = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
+    a, sa = oracle.render(g["flat"], g["cam"], 96, 54, 16, T=np.float32, max_depth=16, rng_mode=oracle.REF_SERIAL,
+                          ref_threads=1, product_order=oracle.PRODUCT_REFERENCE)
+    b, sb = oracle.render(g["flat"], g["cam"], 96, 54, 16, T=np.float32, max_depth=16, n_chunks=16)
+    assert not np.array_equal(a, b)
+    assert np.abs(a.mean(axis=(0, 1)) - b.mean(axis=(0, 1))).max() < 5e-3
+    # un-jittered first sample: identical primary rays => first-sample-only images of sky pixels agree exactly
+    a1, _ = oracle.render(g["flat"], g["cam"], 96, 54, 1, T=np.float32, max_depth=16, rng_mode=oracle.REF_SERIAL,
+                          ref_threads=1, product_order=oracle.PRODUCT_REFERENCE)
+    b1, _ = oracle.render(g["flat"], g["cam"], 96, 54, 1, T=np.float32, max_depth=16, n_chunks=1)
+    assert np.array_equal(a1[:10], b1[:10])     # top rows are pure sky; lens_radius = 0
+    # the image depends on the thread count in REF_SERIAL ...
+    c, _ = oracle.render(g["flat"], g["cam"], 96, 54, 16, T=np.float32, max_depth=16, rng_mode=oracle.REF_SERIAL,
+                         ref_threads=4, product_order=oracle.PRODUCT_REFERENCE)
+    assert not np.array_equal(a, c)
+    # ... but not on how many workers execute those "threads"
+    d, _ = oracle.render(g["flat"], g["cam"], 96, 54, 16, T=np.float32, max_depth=16, rng_mode=oracle.REF_SERIAL,
+                         ref_threads=4, product_order=oracle.PRODUCT_REFERENCE, omp_threads=1)
+    assert np.array_equal(c, d)
+
+
+def test_depth_zero_and_one(oracle):
+    g = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
+    img0, st0 = oracle.render(g["flat"], g["cam"], 96, 54, 2, T=np.float32, max_depth=0)
+    assert np.all(img0 == 0) and st0["segments"] == 0           # src/ray_color.jl:15-17
+    img1, st1 = oracle.render(g["flat"], g["cam"], 96, 54, 2, T=np.float32, max_depth=1)
+    assert st1["segments"] == 96 * 54 * 2                       # exactly one scan per sample
+    assert np.all(img1[40:] == 0)                               # ground hit -> recursion bottoms out -> black
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_host_mirror_matches_oracle_mirror(oracle, rtw, T):
+    """scene_random_spheres / default_camera: Python host mirror == the oracle's C mirror, bit for bit."""
+    rtw.reseed()
+    flat = rtw.flatten_scene(rtw.scene_random_spheres(elem_type=T), T)
+    ref = oracle.scene_random_spheres(1, T)
+    assert flat["n"] == ref["n"] and 480 <= flat["n"] <= 488
+    for k in ("cx", "cy", "cz", "r", "kind", "ar", "ag", "ab", "param"):
+        assert np.array_equal(flat[k], ref[k]), k
+    cams = [(rtw.t_cam1(elem_type=T), ((13, 2, 3), (0, 0, 0), (0, 1, 0), 20, 16 / 9, 0.1, 10.0)),
+            (rtw.t_default_cam(elem_type=T), ((0, 0, 0), (0, 0, -1), (0, 1, 0), 90, 16 / 9, 0, 1)),
+            (rtw.t_cam2(elem_type=T), ((3, 3, 2), (0, 0, -1), (0, 1, 0), 20, 16 / 9, 2.0,
+                                       np.linalg.norm(np.array([3.0, 3, 2]) - np.array([0, 0, -1.0]))))]
+    for cam, args in cams:
+        ref = oracle.default_camera(*args, T)
+        for k in oracle.CAM_FIELDS:
+            assert np.array_equal(getattr(cam, k), ref[k]), k
+        assert cam.lens_radius == ref["lens_radius"]
+
+
+def test_random_scene_composition(rtw):
+    # src/scenes.jl:49-84: ground, lattice minus the spheres near (4,0.2,0), three big spheres
+    rtw.reseed()
+    s = rtw.scene_random_spheres(elem_type=np.float32)
+    assert isinstance(s[0].mat, rtw.Lambertian) and s[0].radius == 1000
+    assert isinstance(s[-3].mat, rtw.Dielectric) and isinstance(s[-2].mat, rtw.Lambertian) and isinstance(s[-1].mat, rtw.Metal)
+    assert s[-1].mat.fuzz == 0
+    fuzz = [x.mat.fuzz for x in s[1:-3] if isinstance(x.mat, rtw.Metal)]
+    assert max(fuzz) > 0.5 and max(fuzz) < 5.0          # reference quirk: fuzz in [0,5)
+    rtw.reseed()
+    s2 = rtw.scene_random_spheres(elem_type=np.float32)
+    assert len(s2) == len(s) and all(np.array_equal(a.center, b.center) for a, b in zip(s, s2))
