@@ -23,6 +23,7 @@
 typedef struct { uint64_t x, y; } orng;
 typedef struct { orng rng; uint64_t draws, segments; } octx;
 typedef struct { double r, g, b; } c3;
+static _Thread_local uint64_t g_cand_disc = 0, g_cand_fwd = 0;   /* workload statistics */
 
 static inline uint64_t rotl64(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
 

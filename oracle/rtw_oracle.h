@@ -95,6 +95,8 @@ typedef struct {
     uint64_t segments;       /* calls of hit(world, ...) == ray segments traced               */
     uint64_t sphere_tests;   /* segments * n                                                  */
     uint64_t rng_draws;      /* u64 outputs consumed                                          */
+    uint64_t cand_disc;      /* sphere tests with disc >= 0 (line meets sphere)               */
+    uint64_t cand_forward;   /* ... of which half_b < 0 or origin inside (can yield a root)   */
 } rtwo_stats;
 
 /* render(): out is H x W x 3 of T, Julia column-major Matrix{RGB{T}}:

@@ -53,7 +53,7 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
-                ("rng_draws", C.c_uint64)]
+                ("rng_draws", C.c_uint64), ("cand_disc", C.c_uint64), ("cand_forward", C.c_uint64)]
 
 
 _lib = None

@@ -75,6 +75,8 @@ static inline int FN(sphere_test_)(V3 c, T r, V3 o, V3 d, T tmin, T tmax, T *t_o
     T nc = FMA_T(-oc.z, oc.z, FMA_T(-oc.y, oc.y, FMA_T(-oc.x, oc.x, r * r))); /* -(:17) */
     T disc = FMA_T(half_b, half_b, nc);                                 /* :18 (a == 1) */
     if (disc < (T)0) return 0;                                          /* :19 */
+    g_cand_disc++;                       /* workload statistics only */
+    if (half_b < (T)0 || nc > (T)0) g_cand_fwd++;
     T sqrtd = SQRT_T(disc);                                             /* :20 */
     T root = -half_b - sqrtd;                                           /* :23 */
     if (root < tmin || tmax < root) {                                   /* :24 */
@@ -284,7 +286,7 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
     if (!w || !cam || !P || !out) return -1;
     if (P->width <= 0 || P->height <= 0 || P->spp <= 0 || w->n < 0) return -2;
     const int W = P->width, H = P->height;
-    uint64_t tot_draws = 0, tot_segments = 0;
+    uint64_t tot_draws = 0, tot_segments = 0, tot_cd = 0, tot_cf = 0;
     int nthr = P->omp_threads > 0 ? P->omp_threads : omp_get_max_threads();
 
     if (P->rng_mode == RTW_RNG_REF_SERIAL) {
@@ -293,13 +295,14 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
          * Xoroshiro128Plus(k) freshly seeded by reseed!() (src/rand.jl:2, src/render.jl:21). */
         int n = P->ref_threads > 0 ? P->ref_threads : 1;
         int len = H / n, rem = H % n;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthr) reduction(+ : tot_draws, tot_segments)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthr) reduction(+ : tot_draws, tot_segments, tot_cd, tot_cf)
         for (int k = 1; k <= n; ++k) {
             int f = 1 + (k - 1) * len, l = f + len - 1;
             if (rem > 0) {
                 if (k <= rem) { f += k - 1; l += k; } else { f += rem; l += rem; }
             }
             octx c; c.draws = 0; c.segments = 0;
+            g_cand_disc = 0; g_cand_fwd = 0;
             rng_seed_int((uint64_t)k, &c.rng);
             for (int i = f; i <= l; ++i)
                 for (int j = 1; j <= W; ++j) {
@@ -312,7 +315,7 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
                     }
                     FN(store_)(P, out, i, j, acc);
                 }
-            tot_draws += c.draws; tot_segments += c.segments;
+            tot_draws += c.draws; tot_segments += c.segments; tot_cd += g_cand_disc; tot_cf += g_cand_fwd;
         }
     } else {
         /* PIXEL_STREAM: one independent Xoroshiro128+ stream per (pixel, sample chunk); the
@@ -321,13 +324,14 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
         int cs = (P->spp + nch - 1) / nch;
         int nch_eff = (P->spp + cs - 1) / cs;
         long npix = (long)W * H;
-#pragma omp parallel for schedule(dynamic, 64) num_threads(nthr) reduction(+ : tot_draws, tot_segments)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthr) reduction(+ : tot_draws, tot_segments, tot_cd, tot_cf)
         for (long pix = 0; pix < npix; ++pix) {
             int j = (int)(pix / H) + 1, i = (int)(pix % H) + 1;
             T u = (T)((double)j / (double)W);
             T v = (T)((double)(H - i) / (double)H);
             c3 acc = {0.0, 0.0, 0.0};
             octx c; c.draws = 0; c.segments = 0;
+            g_cand_disc = 0; g_cand_fwd = 0;
             for (int ch = 0; ch < nch_eff; ++ch) {
                 rng_stream(P->seed, (uint64_t)pix, (uint64_t)ch, &c.rng);
                 c3 cs_sum = {0.0, 0.0, 0.0};
@@ -339,10 +343,11 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
                 acc.r += cs_sum.r; acc.g += cs_sum.g; acc.b += cs_sum.b;
             }
             FN(store_)(P, out, i, j, acc);
-            tot_draws += c.draws; tot_segments += c.segments;
+            tot_draws += c.draws; tot_segments += c.segments; tot_cd += g_cand_disc; tot_cf += g_cand_fwd;
         }
     }
     if (stats) {
+        stats->cand_disc = tot_cd; stats->cand_forward = tot_cf;
         stats->samples = (uint64_t)W * H * (uint64_t)P->spp;
         stats->segments = tot_segments;
         stats->sphere_tests = tot_segments * (uint64_t)w->n;

@@ -223,26 +223,112 @@ __device__ __forceinline__ void get_ray(Rng &rng, const Camera<T> &cam, T s, T t
 // geom[i] = (cx, cy, cz, r*r)   hot: 16 B (f32) / 32 B (f64) per sphere, wave-uniform reads
 // mat0[i] = (r, param, kind, 0) cold: read once per segment by the lane that hit sphere i
 // mat1[i] = (ar, ag, ab, 0)
-// geom is padded to a multiple of RTW_SPHERE_PAD with spheres that can never be hit (r2 < 0).
-#define RTW_SPHERE_PAD 16
+// geom is padded to a multiple of 32 (one candidate-mask word) plus one extra prefetch group
+// with spheres that can never be hit (r*r = -1e30 => discriminant < 0 always).
+#define RTW_SPHERE_WORD 32
+#define RTW_SPHERE_TAIL 8
 template <typename T> struct DevScene {
     const typename Vec4<T>::type *geom;
     const typename Vec4<T>::type *mat0;
     const typename Vec4<T>::type *mat1;
-    int n, n_pad;
+    int n, n_pad;   // n_pad: multiple of RTW_SPHERE_WORD (the tail group lies beyond n_pad)
 };
 
-// src/hit.jl:38-50: closest hit by linear scan; `closest` shrinks; later sphere wins exact ties.
-template <typename T>
-__device__ __forceinline__ int hit_world(const DevScene<T> &w, V3<T> o, V3<T> d, T tmin, T tmax, T &t_hit) {
-    T closest = tmax;
-    int idx = -1;
-    for (int i = 0; i < w.n_pad; ++i) {
-        typename Vec4<T>::type s = w.geom[i];
-        T hb, disc, root;
-        sphere_disc<T>(s.x, s.y, s.z, s.w, o, d, hb, disc);
-        if (sphere_root<T>(hb, disc, tmin, closest, root)) { closest = root; idx = i; }
+// Candidate lists: pass 1 of the scan appends the indices of the spheres whose discriminant is
+// >= 0 to a per-lane list in LDS; pass 2 resolves them in ascending sphere order.
+#define RTW_LIST_CAP 40     // entries per lane (u16)
+#define RTW_LIST_FLUSH 8    // resolve early when any lane holds more than this (cap - word = 8)
+
+__device__ __forceinline__ uint32_t sign_word(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ uint32_t sign_word(double x) { return (uint32_t)((uint64_t)__double_as_longlong(x) >> 32); }
+
+template <typename T> struct ScanGroup;
+template <> struct ScanGroup<float> { static constexpr int N = 8; };    // 8 x 16 B = 2 x s_load_dwordx16
+template <> struct ScanGroup<double> { static constexpr int N = 4; };   // 4 x 32 B = 2 x s_load_dwordx16
+
+// src/hit.jl:38-50 -- closest hit by linear scan over ALL spheres; `closest` shrinks; a later
+// sphere wins an exact tie.  Same results as the plain loop, organised for the wave:
+//   pass 1  (branch-free, every lane, every sphere): the discriminant of src/hit.jl:13-18 from
+//           wave-uniform sphere data held in SGPRs (scalar loads, prefetched one group ahead);
+//           its sign bit is shifted into a 32-sphere mask word with ONE v_alignbit per sphere.
+//           disc >= 0  <=>  sign bit clear (disc is never -0: hb*hb >= +0; NaN cannot occur for
+//           finite scenes).  After each word the few candidate indices go to the lane's LDS list.
+//   pass 2  (every lane walks its own list, ascending sphere index): the exact root selection
+//           of src/hit.jl:19-29 against the shrinking `closest`.  Sphere order is preserved, so
+//           ties resolve exactly as in the reference.
+template <typename T, int STRIDE>
+__device__ __forceinline__ void resolve_candidates(const DevScene<T> &w, V3<T> o, V3<T> d, T tmin, T &closest,
+                                                   int &idx, const unsigned short *list, int cnt) {
+    for (int c = 0; __any(c < cnt); ++c) {
+        if (c < cnt) {
+            const int i = list[c * STRIDE];
+            const typename Vec4<T>::type s = w.geom[i];
+            T hb, disc, root;
+            sphere_disc<T>(s.x, s.y, s.z, s.w, o, d, hb, disc);
+            if (sphere_root<T>(hb, disc, tmin, closest, root)) { closest = root; idx = i; }
+        }
     }
+}
+
+template <typename T, int STRIDE>
+__device__ __forceinline__ int hit_world(const DevScene<T> &w, V3<T> o, V3<T> d, T tmin, T tmax, T &t_hit,
+                                         unsigned short *list) {
+    using V4 = typename Vec4<T>::type;
+    constexpr int G = ScanGroup<T>::N;
+    typedef const T __attribute__((address_space(4))) *cptr;    // constant address space: SMEM loads
+    cptr gs = (cptr)(uintptr_t)w.geom;
+    auto ldg = [&](int i) -> V4 { return V4{gs[4 * i], gs[4 * i + 1], gs[4 * i + 2], gs[4 * i + 3]}; };
+    T closest = tmax;
+    int idx = -1, cnt = 0;
+    V4 A[G], B[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) A[k] = ldg(k);
+    // One sphere: discriminant + sign bit into the mask word (11 VALU ops).
+    auto test1 = [&](const V4 &sp, uint32_t &mask) {
+        T hb, disc;
+        sphere_disc<T>(sp.x, sp.y, sp.z, sp.w, o, d, hb, disc);
+        mask = __builtin_amdgcn_alignbit(mask, sign_word(disc), 31);
+    };
+    for (int base = 0; base < w.n_pad; base += RTW_SPHERE_WORD) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int q = 0; q < RTW_SPHERE_WORD / (2 * G); ++q) {
+            const int off = base + q * 2 * G;
+            // Scalar loads return out of order, so every wait is lgkmcnt(0).  To keep a group's
+            // loads in flight for a whole group of VALU work, the next group's loads are issued
+            // right AFTER the wait that the current group's first use forces, never before it.
+            test1(A[0], mask);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < G; ++k) B[k] = ldg(off + G + k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 1; k < G; ++k) test1(A[k], mask);
+            __builtin_amdgcn_sched_barrier(0);
+            test1(B[0], mask);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < G; ++k) A[k] = ldg(off + 2 * G + k);      // next group (tail-padded)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 1; k < G; ++k) test1(B[k], mask);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t m = ~mask;                       // bit 31 = sphere `base`, bit 0 = sphere base+31
+        while (__any(m != 0u)) {
+            if (m != 0u) {
+                const int b = __clz((int)m);
+                list[cnt * STRIDE] = (unsigned short)(base + b);
+                cnt += 1;
+                m &= ~(0x80000000u >> b);
+            }
+        }
+        if (__any(cnt > RTW_LIST_FLUSH)) {
+            resolve_candidates<T, STRIDE>(w, o, d, tmin, closest, idx, list, cnt);
+            cnt = 0;
+        }
+    }
+    resolve_candidates<T, STRIDE>(w, o, d, tmin, closest, idx, list, cnt);
     t_hit = closest;
     return idx;
 }

@@ -113,9 +113,11 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     HIP_TRY(hipSetDevice(dev));
     using V4 = typename rtw::Vec4<T>::type;
     const int n = s->n;
-    const int n_pad = ((n + RTW_SPHERE_PAD - 1) / RTW_SPHERE_PAD) * RTW_SPHERE_PAD + (n == 0 ? RTW_SPHERE_PAD : 0);
-    std::vector<V4> geom(n_pad), mat0(n_pad), mat1(n_pad);
-    for (int i = 0; i < n_pad; ++i) {
+    const int n_pad = ((n + RTW_SPHERE_WORD - 1) / RTW_SPHERE_WORD) * RTW_SPHERE_WORD;   // 0 spheres: no scan at all
+    const int n_alloc = n_pad + RTW_SPHERE_TAIL;                                          // prefetch tail group
+    if (n_pad >= 65536) return fail(-5, "too many spheres (%d): candidate lists hold 16-bit indices", n);
+    std::vector<V4> geom(n_alloc), mat0(n_alloc), mat1(n_alloc);
+    for (int i = 0; i < n_alloc; ++i) {
         if (i < n) {
             geom[i] = V4{s->cx[i], s->cy[i], s->cz[i], s->r[i] * s->r[i]};  // r^2: src/hit.jl:17
             mat0[i] = V4{s->r[i], s->param[i], (T)s->kind[i], (T)0};
@@ -130,7 +132,7 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     rtw_scene_dev *h = new rtw_scene_dev();
     h->device = dev; h->is_f64 = sizeof(T) == 8; h->n = n; h->n_pad = n_pad;
     h->geom = h->mat0 = h->mat1 = nullptr;
-    const size_t bytes = sizeof(V4) * (size_t)n_pad;
+    const size_t bytes = sizeof(V4) * (size_t)n_alloc;
     HIP_TRY(hipMalloc(&h->geom, bytes));
     HIP_TRY(hipMalloc(&h->mat0, bytes));
     HIP_TRY(hipMalloc(&h->mat1, bytes));

@@ -41,6 +41,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,
                                                    double *__restrict__ partial, DevCounters *ctr) {
     const unsigned lane = lane_id();
+    __shared__ unsigned short s_list[RTW_LIST_CAP * 256];   // per-lane candidate lists, stride 256
+    unsigned short *my_list = s_list + threadIdx.x;
 
     // ---- per-lane state ----
     bool alive = true;        // still pulling work
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void trace_kernel(KParams P, Camera<T> cam, De
         T t_hit = 0;
         int idx = -1;
         if (has_ray) {
-            idx = hit_world(scene, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit);
+            idx = hit_world<T, 256>(scene, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list);
             my_segments += 1;
         }
 

@@ -54,9 +54,12 @@ template <typename T>
 __global__ void unit_kernel(int op, int count, const double *__restrict__ in, double *__restrict__ out,
                             DevScene<T> scene, Camera<T> cam) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= count) return;
+    __shared__ unsigned short s_list[RTW_LIST_CAP * 64];    // launched with 64-thread blocks
+    unsigned short *my_list = s_list + threadIdx.x;
+    const bool live = gid < count;                          // no early return: the scan is wave-cooperative
     const double *x = in + (size_t)gid * unit_in_slots(op);
     double *y = out + (size_t)gid * unit_out_slots(op);
+    if (op != U_HIT_WORLD && op != U_RAY_COLOR && !live) return;
     switch (op) {
         case U_HIT_SPHERE: {
             V3<T> c = ld3<T>(x), o = ld3<T>(x + 4), d = ld3<T>(x + 7);
@@ -99,9 +102,12 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
             y[0] = as_f64(rng.x); y[1] = as_f64(rng.y);
         } break;
         case U_HIT_WORLD: {
-            V3<T> o = ld3<T>(x), d = ld3<T>(x + 3);
+            V3<T> o = {0, 0, 0}, d = {0, 0, 1};
+            T tmn = 0, tmx = 0;
+            if (live) { o = ld3<T>(x); d = ld3<T>(x + 3); tmn = (T)x[6]; tmx = (T)x[7]; }
             T t_hit;
-            int idx = hit_world(scene, o, d, (T)x[6], (T)x[7], t_hit);
+            int idx = hit_world<T, 64>(scene, o, d, tmn, tmx, t_hit, my_list);
+            if (!live) return;
             for (int k = 0; k < 9; ++k) y[k] = 0.0;
             y[0] = (double)idx;
             if (idx >= 0) {
@@ -114,19 +120,23 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
         } break;
         case U_RAY_COLOR: {
             // src/ray_color.jl:14-38 as the iterative front-to-back loop of the trace kernel
-            Rng rng = {as_u64(x[0]), as_u64(x[1])};
-            V3<T> o = ld3<T>(x + 2), d = ld3<T>(x + 5);
-            int depth = (int)x[8];
+            Rng rng = {1, 2};
+            V3<T> o = {0, 0, 0}, d = {0, 0, 1};
+            int depth = 0;
+            if (live) { rng = {as_u64(x[0]), as_u64(x[1])}; o = ld3<T>(x + 2); d = ld3<T>(x + 5); depth = (int)x[8]; }
             double tr = 1, tg = 1, tb = 1, cr = 0, cg = 0, cb = 0;
             unsigned segs = 0;
-            while (depth > 0) {
+            bool active = depth > 0;
+            while (__any(active)) {                   // the scan is wave-cooperative: all lanes enter it
                 T t_hit;
-                int idx = hit_world(scene, o, d, (T)1e-4, (T)__builtin_huge_val(), t_hit);
+                int idx = hit_world<T, 64>(scene, o, d, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list);
+                if (!active) continue;
                 segs++;
                 if (idx < 0) {
                     C3 sky = skycolor(d);
                     cr = tr * sky.r; cg = tg * sky.g; cb = tb * sky.b;
-                    break;
+                    active = false;
+                    continue;
                 }
                 auto g = scene.geom[idx];
                 auto m0 = scene.mat0[idx];
@@ -138,7 +148,9 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
                 tr = tr * (double)att.x; tg = tg * (double)att.y; tb = tb * (double)att.z;
                 o = rec.p; d = nd;
                 depth -= 1;
+                if (depth <= 0) active = false;
             }
+            if (!live) return;
             y[0] = as_f64(rng.x); y[1] = as_f64(rng.y);
             y[2] = cr; y[3] = cg; y[4] = cb; y[5] = (double)segs;
         } break;
