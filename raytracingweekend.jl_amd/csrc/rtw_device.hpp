@@ -236,8 +236,10 @@ template <typename T> struct DevScene {
 
 // Candidate lists: pass 1 of the scan appends the indices of the spheres whose discriminant is
 // >= 0 to a per-lane list in LDS; pass 2 resolves them in ascending sphere order.
-#define RTW_LIST_CAP 40     // entries per lane (u16)
-#define RTW_LIST_FLUSH 8    // resolve early when any lane holds more than this (cap - word = 8)
+#define RTW_LIST_CAP 16     // entries per lane (u16); a full list is resolved early (wave-wide)
+// Scenes up to this many bytes of geom are also staged in LDS so that pass 2 gathers its
+// candidates' spheres from LDS (latency ~100 cycles) instead of global memory (~700).
+#define RTW_LDS_SCENE_MAX_BYTES (24 * 1024)
 
 __device__ __forceinline__ uint32_t sign_word(float x) { return __float_as_uint(x); }
 __device__ __forceinline__ uint32_t sign_word(double x) { return (uint32_t)((uint64_t)__double_as_longlong(x) >> 32); }
@@ -245,6 +247,8 @@ __device__ __forceinline__ uint32_t sign_word(double x) { return (uint32_t)((uin
 template <typename T> struct ScanGroup;
 template <> struct ScanGroup<float> { static constexpr int N = 8; };    // 8 x 16 B = 2 x s_load_dwordx16
 template <> struct ScanGroup<double> { static constexpr int N = 4; };   // 4 x 32 B = 2 x s_load_dwordx16
+
+struct NoClock { __device__ __forceinline__ void lap(int) {} };
 
 // src/hit.jl:38-50 -- closest hit by linear scan over ALL spheres; `closest` shrinks; a later
 // sphere wins an exact tie.  Same results as the plain loop, organised for the wave:
@@ -255,14 +259,21 @@ template <> struct ScanGroup<double> { static constexpr int N = 4; };   // 4 x 3
 //           finite scenes).  After each word the few candidate indices go to the lane's LDS list.
 //   pass 2  (every lane walks its own list, ascending sphere index): the exact root selection
 //           of src/hit.jl:19-29 against the shrinking `closest`.  Sphere order is preserved, so
-//           ties resolve exactly as in the reference.
-template <typename T, int STRIDE>
-__device__ __forceinline__ void resolve_candidates(const DevScene<T> &w, V3<T> o, V3<T> d, T tmin, T &closest,
-                                                   int &idx, const unsigned short *list, int cnt) {
+//           ties resolve exactly as in the reference.  `src` is the scene copy in LDS (or the
+//           global array for scenes too large for LDS); the loop is software-pipelined: entry
+//           c+1's index and sphere are fetched while entry c is tested.
+template <typename T, int STRIDE, typename SRC>
+__device__ __forceinline__ void resolve_candidates(SRC src, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
+                                                   const unsigned short *list, int cnt) {
+    using V4 = typename Vec4<T>::type;
+    int i_next = cnt > 0 ? (int)list[0] : 0;
+    V4 s_next = src[i_next];
     for (int c = 0; __any(c < cnt); ++c) {
+        const int i = i_next;
+        const V4 s = s_next;
+        i_next = (c + 1 < cnt) ? (int)list[(c + 1) * STRIDE] : 0;
+        s_next = src[i_next];
         if (c < cnt) {
-            const int i = list[c * STRIDE];
-            const typename Vec4<T>::type s = w.geom[i];
             T hb, disc, root;
             sphere_disc<T>(s.x, s.y, s.z, s.w, o, d, hb, disc);
             if (sphere_root<T>(hb, disc, tmin, closest, root)) { closest = root; idx = i; }
@@ -270,9 +281,9 @@ __device__ __forceinline__ void resolve_candidates(const DevScene<T> &w, V3<T> o
     }
 }
 
-template <typename T, int STRIDE>
-__device__ __forceinline__ int hit_world(const DevScene<T> &w, V3<T> o, V3<T> d, T tmin, T tmax, T &t_hit,
-                                         unsigned short *list) {
+template <typename T, int STRIDE, typename SRC, typename CLK = NoClock>
+__device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o, V3<T> d, T tmin, T tmax, T &t_hit,
+                                         unsigned short *list, CLK &&clk = NoClock()) {
     using V4 = typename Vec4<T>::type;
     constexpr int G = ScanGroup<T>::N;
     typedef const T __attribute__((address_space(4))) *cptr;    // constant address space: SMEM loads
@@ -314,8 +325,15 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, V3<T> o, V3<T> d,
             for (int k = 1; k < G; ++k) test1(B[k], mask);
             __builtin_amdgcn_sched_barrier(0);
         }
+        clk.lap(2);
         uint32_t m = ~mask;                       // bit 31 = sphere `base`, bit 0 = sphere base+31
         while (__any(m != 0u)) {
+            if (__any(cnt >= RTW_LIST_CAP)) {     // some lane's list is full: resolve all lists now
+                clk.lap(4);
+                resolve_candidates<T, STRIDE>(src, o, d, tmin, closest, idx, list, cnt);
+                cnt = 0;
+                clk.lap(5);
+            }
             if (m != 0u) {
                 const int b = __clz((int)m);
                 list[cnt * STRIDE] = (unsigned short)(base + b);
@@ -323,14 +341,19 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, V3<T> o, V3<T> d,
                 m &= ~(0x80000000u >> b);
             }
         }
-        if (__any(cnt > RTW_LIST_FLUSH)) {
-            resolve_candidates<T, STRIDE>(w, o, d, tmin, closest, idx, list, cnt);
-            cnt = 0;
-        }
+        clk.lap(4);
     }
-    resolve_candidates<T, STRIDE>(w, o, d, tmin, closest, idx, list, cnt);
+    resolve_candidates<T, STRIDE>(src, o, d, tmin, closest, idx, list, cnt);
+    clk.lap(5);
     t_hit = closest;
     return idx;
+}
+
+// Stage the scene's geom array into LDS (all threads of the block; caller synchronises).
+template <typename T>
+__device__ __forceinline__ void stage_scene(const DevScene<T> &w, typename Vec4<T>::type *dst) {
+    const int n_alloc = w.n_pad + RTW_SPHERE_TAIL;
+    for (int i = threadIdx.x; i < n_alloc; i += blockDim.x) dst[i] = w.geom[i];
 }
 
 }  // namespace rtw

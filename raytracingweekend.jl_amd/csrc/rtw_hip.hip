@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -204,8 +205,16 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     S.n = scene->n; S.n_pad = scene->n_pad;
 
     // persistent grid: enough 256-thread blocks to fill every CU at the kernel's occupancy
+    static const bool phase_profile = getenv("RTW_PHASE_PROFILE") != nullptr;   // debugging aid, not for timed runs
+    const size_t list_bytes = (size_t)RTW_LIST_CAP * 256 * sizeof(unsigned short);
+    const size_t geom_bytes = (size_t)(scene->n_pad + RTW_SPHERE_TAIL) * sizeof(V4);
+    const bool lds_scene = geom_bytes <= RTW_LDS_SCENE_MAX_BYTES;
+    const size_t lds_bytes = list_bytes + (lds_scene ? geom_bytes : 0);
+    typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, double *, rtw::DevCounters *);
+    kern_t kern = phase_profile ? (lds_scene ? (kern_t)rtw::trace_kernel<T, true, true> : (kern_t)rtw::trace_kernel<T, true, false>)
+                                : (lds_scene ? (kern_t)rtw::trace_kernel<T, false, true> : (kern_t)rtw::trace_kernel<T, false, false>);
     int blocks_per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, rtw::trace_kernel<T>, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 256, lds_bytes));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     long long grid = (long long)ctx->num_cus * blocks_per_cu;
     const long long max_useful = (total_items + 255) / 256;
@@ -215,7 +224,7 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     HIP_TRY(hipMemsetAsync(ctx->ctr, 0, sizeof(rtw::DevCounters), stream));
     HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)p->width * p->height * 3 * sizeof(T), stream));
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(rtw::trace_kernel<T>, dim3((unsigned)grid), dim3(256), 0, stream, K, C, S, ctx->partial, ctx->ctr);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, ctx->partial, ctx->ctr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
     const unsigned n_pix_local = (unsigned)n_local * 64u;
@@ -354,6 +363,13 @@ int rtw_stats(rtw_stats_t *out) {
     HIP_TRY(hipEventElapsedTime(&t_ms, ctx->ev0, ctx->ev2));
     rtw::DevCounters c;
     HIP_TRY(hipMemcpy(&c, ctx->ctr, sizeof c, hipMemcpyDeviceToHost));
+    if (getenv("RTW_PHASE_PROFILE")) {
+        double tot = 0;
+        for (int k = 0; k < 6; ++k) tot += (double)c.phase[k];
+        fprintf(stderr, "[rtw phase profile] wave-cycles: pull %.1f%%  raygen %.1f%%  scan-pass1 %.1f%%  extract %.1f%%  resolve %.1f%%  shade %.1f%%  (total %.3g)\n",
+                100 * c.phase[0] / tot, 100 * c.phase[1] / tot, 100 * c.phase[2] / tot, 100 * c.phase[4] / tot,
+                100 * c.phase[5] / tot, 100 * c.phase[3] / tot, tot);
+    }
     memset(out, 0, sizeof *out);
     out->samples = c.samples;
     out->segments = c.segments;

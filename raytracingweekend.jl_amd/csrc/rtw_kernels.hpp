@@ -33,16 +33,38 @@ struct DevCounters {
     unsigned long long next_item;
     unsigned long long segments;
     unsigned long long samples;
+    unsigned long long phase[8];   // RTW_PHASE_PROFILE=1 only: wave-cycles per phase (s_memtime)
+};
+
+// Phase profiler (opt-in instantiation, never used for timed runs): s_memtime stamps around
+// the phases of the lane loop, summed per wave.
+template <bool ON> struct PhaseClock {
+    unsigned long long t0 = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __device__ __forceinline__ void start() { if (ON) t0 = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void lap(int k) {
+        if (ON) { unsigned long long t = __builtin_readcyclecounter(); acc[k] += t - t0; t0 = t; }
+    }
 };
 
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-template <typename T>
+#define RTW_ITEM_BATCH 64u   // work items a wave takes from the global queue per atomic
+
+template <typename T, bool PROFILE, bool LDS_SCENE>
 __global__ __launch_bounds__(256) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,
                                                    double *__restrict__ partial, DevCounters *ctr) {
+    using V4 = typename Vec4<T>::type;
     const unsigned lane = lane_id();
-    __shared__ unsigned short s_list[RTW_LIST_CAP * 256];   // per-lane candidate lists, stride 256
-    unsigned short *my_list = s_list + threadIdx.x;
+    // LDS: [per-lane candidate lists, stride 256][scene geom copy (LDS_SCENE only)]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short *my_list = reinterpret_cast<unsigned short *>(smem) + threadIdx.x;
+    V4 *lds_geom = reinterpret_cast<V4 *>(smem + RTW_LIST_CAP * 256 * sizeof(unsigned short));
+    if (LDS_SCENE) {
+        stage_scene<T>(scene, lds_geom);
+        __syncthreads();
+    }
+    // the wave's local pool of work items [pool_next, pool_end): one global atomic per batch
+    unsigned pool_next = 0, pool_end = 0;
 
     // ---- per-lane state ----
     bool alive = true;        // still pulling work
@@ -62,16 +84,22 @@ __global__ __launch_bounds__(256) void trace_kernel(KParams P, Camera<T> cam, De
     const T inv_w_div = (T)(float)P.width;   // f32_image_width  (src/render.jl:16)
     const T inv_h_div = (T)(float)P.height;  // f32_image_height (src/render.jl:17)
 
+    PhaseClock<PROFILE> clk;
     for (;;) {
+        clk.start();
         // ---- (A) lanes whose chunk is done flush it and pull the next item ----
         const bool need = alive && !has_ray && samples_left == 0;
         const unsigned long long need_mask = __ballot(need);
         if (need_mask) {
             const unsigned cnt = __popcll(need_mask);
-            const unsigned leader = __ffsll((long long)need_mask) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&ctr->next_item, (unsigned long long)cnt);
-            base = __shfl(base, leader);
+            const unsigned avail = pool_end - pool_next;
+            unsigned new_base = 0;
+            if (cnt > avail) {                                   // wave-uniform: refill the pool
+                unsigned long long got = 0;
+                if (lane == 0) got = atomicAdd(&ctr->next_item, (unsigned long long)RTW_ITEM_BATCH);
+                got = __shfl(got, 0);
+                new_base = got > 0xffffffffull ? 0xffffffffu : (unsigned)got;   // beyond total_items anyway
+            }
             if (need) {
                 if (have_item) {
                     double *dst = partial + (size_t)item_slot * 3;
@@ -79,7 +107,8 @@ __global__ __launch_bounds__(256) void trace_kernel(KParams P, Camera<T> cam, De
                     have_item = false;
                 }
                 const unsigned rank = __popcll(need_mask & ((1ull << lane) - 1ull));
-                const unsigned long long idx = base + rank;
+                const unsigned long long idx = rank < avail ? (unsigned long long)pool_next + rank
+                                                            : (unsigned long long)new_base + (rank - avail);
                 if (idx >= P.total_items) {
                     alive = false;
                 } else {
@@ -106,8 +135,16 @@ __global__ __launch_bounds__(256) void trace_kernel(KParams P, Camera<T> cam, De
                     // out-of-image pixel of an edge tile: nothing to do, pull again next round
                 }
             }
+            if (cnt > avail) {
+                pool_next = new_base + (cnt - avail);
+                pool_end = new_base > 0xffffffffu - RTW_ITEM_BATCH ? 0xffffffffu : new_base + RTW_ITEM_BATCH;
+                if (pool_next > pool_end) pool_next = pool_end;
+            } else {
+                pool_next += cnt;
+            }
         }
         if (!__any(alive)) break;
+        clk.lap(0);
 
         // ---- (B) start the next sample (src/render.jl:29-37) ----
         if (alive && !has_ray && samples_left > 0) {
@@ -126,14 +163,19 @@ __global__ __launch_bounds__(256) void trace_kernel(KParams P, Camera<T> cam, De
             my_samples += 1;
         }
 
+        clk.lap(1);
         // ---- (C) closest hit over the whole sphere list (src/hit.jl:38-50) ----
         T t_hit = 0;
         int idx = -1;
         if (has_ray) {
-            idx = hit_world<T, 256>(scene, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list);
+            if (LDS_SCENE)
+                idx = hit_world<T, 256>(scene, (const V4 *)lds_geom, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list, clk);
+            else
+                idx = hit_world<T, 256>(scene, scene.geom, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list, clk);
             my_segments += 1;
         }
 
+        clk.lap(2);
         // ---- (D) shade (src/ray_color.jl:20-37) ----
         if (has_ray) {
             if (idx < 0) {
@@ -154,8 +196,12 @@ __global__ __launch_bounds__(256) void trace_kernel(KParams P, Camera<T> cam, De
                 if (depth_left <= 0) has_ray = false;   // recursion bottoms out with 0 radiance
             }
         }
+        clk.lap(3);
     }
 
+    if (PROFILE && lane == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd(&ctr->phase[k], clk.acc[k]);
+    }
     // counters (one atomic per lane at the very end; the compiler reduces them per wave)
     atomicAdd(&ctr->segments, (unsigned long long)my_segments);
     atomicAdd(&ctr->samples, (unsigned long long)my_samples);

@@ -106,7 +106,7 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
             T tmn = 0, tmx = 0;
             if (live) { o = ld3<T>(x); d = ld3<T>(x + 3); tmn = (T)x[6]; tmx = (T)x[7]; }
             T t_hit;
-            int idx = hit_world<T, 64>(scene, o, d, tmn, tmx, t_hit, my_list);
+            int idx = hit_world<T, 64>(scene, scene.geom, o, d, tmn, tmx, t_hit, my_list);
             if (!live) return;
             for (int k = 0; k < 9; ++k) y[k] = 0.0;
             y[0] = (double)idx;
@@ -129,7 +129,7 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
             bool active = depth > 0;
             while (__any(active)) {                   // the scan is wave-cooperative: all lanes enter it
                 T t_hit;
-                int idx = hit_world<T, 64>(scene, o, d, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list);
+                int idx = hit_world<T, 64>(scene, scene.geom, o, d, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list);
                 if (!active) continue;
                 segs++;
                 if (idx < 0) {

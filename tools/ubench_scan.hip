@@ -193,6 +193,33 @@ struct V7 {
     }
 };
 
+// ---- variant 9: pass-1 VALU work only: sphere data stays in SGPRs, no SMEM in the loop --------
+// (upper bound for pass 1 if scalar-load latency were free; results are NOT comparable to v0)
+struct V9 {
+    static constexpr const char *name = "v9 pass-1 VALU only (no SMEM in loop; bound, not a scan)";
+    static constexpr int lds_bytes = 0;
+    __device__ static Hit scan(const float4 *__restrict__ g, const float4 *, int n, Ray r) {
+        float4 A[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) A[k] = g[k];
+        unsigned acc = 0;
+        for (int base = 0; base < n; base += 32) {
+            unsigned mask = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    asm volatile("" : "+s"(A[k].x), "+s"(A[k].y), "+s"(A[k].z), "+s"(A[k].w));
+                    float hb, dc; disc_of(A[k], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, hb, dc);
+                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(dc), 31);
+                }
+            }
+            acc += __popc(mask);
+        }
+        return {(int)acc, 0.f};
+    }
+};
+
 // ---- variant 6: two rays per lane, scalar loads ----------------------------------------------
 // (handled by a separate kernel below)
 
@@ -290,7 +317,7 @@ int main(int argc, char **argv) {
     for (int k = 0; k < 8; ++k) g.push_back({0, 0, 0, -1e30f});   // prefetch tail for v7
     const int blocks = prop.multiProcessorCount * 8, threads = 256, lanes = blocks * threads;
     size_t nrays = (size_t)lanes * rays_per_lane;
-    std::vector<Ray> cam(nrays), dif(nrays);
+    std::vector<Ray> cam(nrays), dif(nrays), mis(nrays);
     for (size_t i = 0; i < nrays; ++i) {
         // coherent: camera rays, consecutive lanes = neighbouring pixels
         size_t lane = i % lanes; int px = (int)(lane % 1920), py = (int)((lane / 1920) % 1080);
@@ -306,6 +333,7 @@ int main(int argc, char **argv) {
         do { ax = 2 * (float)urand() - 1; ay = 2 * (float)urand() - 1; az = 2 * (float)urand() - 1; q = ax * ax + ay * ay + az * az; } while (q > 1 || q < 1e-4f);
         l = 1 / sqrtf(q); if (urand() < 0.85) ay = fabsf(ay);
         dif[i] = {ox, oy, oz, ax * l, ay * l, az * l};
+        mis[i] = {ox, 3.0f + oy, oz, ax * l, fabsf(ay) * l + 1e-3f, az * l};   // above everything, going up: disc < 0 for every sphere
     }
     float4 *d_g; Ray *d_r; Hit *d_o0, *d_o;
     CHECK(hipMalloc(&d_g, (n + 8) * sizeof(float4))); CHECK(hipMalloc(&d_r, nrays * sizeof(Ray)));
@@ -327,14 +355,14 @@ int main(int argc, char **argv) {
         printf("  %-8s %-58s %8.3f ms  %7.1f Gtests/s  %5.1f%% of FP32 VALU peak (17 flop/test)\n", set, name, best,
                tests / best / 1e6, 100.0 * tests * 17 / (best * 1e-3) / 157.3e12);
     };
-    for (int set = 0; set < 2; ++set) {
-        const char *sname = set ? "bounce" : "camera";
-        CHECK(hipMemcpy(d_r, (set ? dif : cam).data(), nrays * sizeof(Ray), hipMemcpyHostToDevice));
+    for (int set = 0; set < 3; ++set) {
+        const char *sname = set == 2 ? "miss" : set ? "bounce" : "camera";
+        CHECK(hipMemcpy(d_r, (set == 2 ? mis : set ? dif : cam).data(), nrays * sizeof(Ray), hipMemcpyHostToDevice));
 #define RUNV(V, ISREF)                                                                                              \
         run([&](Hit *dst) { hipLaunchKernelGGL(scan_kernel<V>, dim3(blocks), dim3(threads), V::lds_bytes, 0, d_g, n, d_r, rays_per_lane, dst); }, V::name, ISREF ? d_o0 : d_o, sname); \
         if (!ISREF) { CHECK(hipMemcpy(h.data(), d_o, lanes * sizeof(Hit), hipMemcpyDeviceToHost)); size_t bad = 0; for (int i = 0; i < lanes; ++i) bad += (h[i].idx != h0[i].idx || h[i].t != h0[i].t); if (bad) printf("      MISMATCH vs v0 on %zu lanes\n", bad); } \
         else { CHECK(hipMemcpy(h0.data(), d_o0, lanes * sizeof(Hit), hipMemcpyDeviceToHost)); long hits = 0; for (int i = 0; i < lanes; ++i) hits += h0[i].idx; printf("      (checksum %ld)\n", hits); }
-        RUNV(V0, true) RUNV(V1, false) RUNV(V2, false) RUNV(V3, false) RUNV(V4, false) RUNV(V5, false) RUNV(V7, false)
+        RUNV(V0, true) RUNV(V1, false) RUNV(V2, false) RUNV(V3, false) RUNV(V4, false) RUNV(V5, false) RUNV(V7, false) RUNV(V9, false)
         run([&](Hit *dst) { hipLaunchKernelGGL(scan2_kernel, dim3(blocks), dim3(threads), 0, 0, d_g, n, d_r, rays_per_lane, dst); }, "v6 scalar-load, 2 rays/lane, 4 spheres/iter", d_o, sname);
         CHECK(hipMemcpy(h.data(), d_o, lanes * sizeof(Hit), hipMemcpyDeviceToHost));
         { size_t bad = 0; for (int i = 0; i < lanes; ++i) bad += (h[i].idx != h0[i].idx); if (bad) printf("      MISMATCH(idx sum) vs v0 on %zu lanes\n", bad); }
