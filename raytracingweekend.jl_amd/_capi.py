@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librtw_hip.so")
+LIB_PATH = os.environ.get("RTW_HIP_LIB") or os.path.join(_HERE, "lib", "librtw_hip.so")   # env: kernel A/B experiments only
 
 #: every symbol include/rtw_hip.h declares
 SYMBOLS = [

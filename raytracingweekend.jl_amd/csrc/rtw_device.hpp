@@ -223,7 +223,7 @@ __device__ __forceinline__ void get_ray(Rng &rng, const Camera<T> &cam, T s, T t
 // geom[i] = (cx, cy, cz, r*r)   hot: 16 B (f32) / 32 B (f64) per sphere, wave-uniform reads
 // mat0[i] = (r, param, kind, 0) cold: read once per segment by the lane that hit sphere i
 // mat1[i] = (ar, ag, ab, 0)
-// geom is padded to a multiple of 32 (one candidate-mask word) plus one extra prefetch group
+// geom is padded to a multiple of 2*G spheres (one software-pipeline pair) plus one prefetch group
 // with spheres that can never be hit (r*r = -1e30 => discriminant < 0 always).
 #define RTW_SPHERE_WORD 32
 #define RTW_SPHERE_TAIL 8
@@ -231,7 +231,7 @@ template <typename T> struct DevScene {
     const typename Vec4<T>::type *geom;
     const typename Vec4<T>::type *mat0;
     const typename Vec4<T>::type *mat1;
-    int n, n_pad;   // n_pad: multiple of RTW_SPHERE_WORD (the tail group lies beyond n_pad)
+    int n, n_pad;   // n_pad: multiple of 2*ScanGroup<T>::N (the tail group lies beyond n_pad)
 };
 
 // Candidate lists: pass 1 of the scan appends the indices of the spheres whose discriminant is
@@ -302,8 +302,10 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
     };
     for (int base = 0; base < w.n_pad; base += RTW_SPHERE_WORD) {
         uint32_t mask = 0;
-#pragma unroll
-        for (int q = 0; q < RTW_SPHERE_WORD / (2 * G); ++q) {
+        // the last word may be partial: n_pad is a multiple of one pair of groups (2G), not of 32
+        const int left = w.n_pad - base;
+        const int npairs = left >= RTW_SPHERE_WORD ? RTW_SPHERE_WORD / (2 * G) : left / (2 * G);
+        for (int q = 0; q < npairs; ++q) {
             const int off = base + q * 2 * G;
             // Scalar loads return out of order, so every wait is lgkmcnt(0).  To keep a group's
             // loads in flight for a whole group of VALU work, the next group's loads are issued
@@ -327,6 +329,7 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
         }
         clk.lap(2);
         uint32_t m = ~mask;                       // bit 31 = sphere `base`, bit 0 = sphere base+31
+        if (left < RTW_SPHERE_WORD) m <<= (RTW_SPHERE_WORD - npairs * 2 * G);   // partial word: align to bit 31
         while (__any(m != 0u)) {
             if (__any(cnt >= RTW_LIST_CAP)) {     // some lane's list is full: resolve all lists now
                 clk.lap(4);

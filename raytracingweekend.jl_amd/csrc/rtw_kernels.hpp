@@ -48,10 +48,17 @@ template <bool ON> struct PhaseClock {
 
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// waves per SIMD the trace kernel is compiled for (second __launch_bounds__ argument):
+// Float32 -> 7 (VGPR cap 72), Float64 -> 4 (cap 128; the double state does not fit lower caps)
+#ifndef RTW_TRACE_WAVES_F32
+#define RTW_TRACE_WAVES_F32 7
+#endif
+template <typename T> struct TraceWaves { static constexpr int value = RTW_TRACE_WAVES_F32; };
+template <> struct TraceWaves<double> { static constexpr int value = 4; };
 #define RTW_ITEM_BATCH 64u   // work items a wave takes from the global queue per atomic
 
 template <typename T, bool PROFILE, bool LDS_SCENE>
-__global__ __launch_bounds__(256) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,
+__global__ __launch_bounds__(256, TraceWaves<T>::value) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,
                                                    double *__restrict__ partial, DevCounters *ctr) {
     using V4 = typename Vec4<T>::type;
     const unsigned lane = lane_id();

@@ -188,7 +188,7 @@ struct V7 {
         rtw::DevScene<float> w{g, nullptr, nullptr, n, n};
         unsigned short *list = (unsigned short *)lds_raw + threadIdx.x;
         float t;
-        int idx = rtw::hit_world<float, 256>(w, rtw::V3<float>{r.ox, r.oy, r.oz}, rtw::V3<float>{r.dx, r.dy, r.dz}, 1e-4f, INFINITY, t, list);
+        int idx = rtw::hit_world<float, 256>(w, g, rtw::V3<float>{r.ox, r.oy, r.oz}, rtw::V3<float>{r.dx, r.dy, r.dz}, 1e-4f, INFINITY, t, list);
         return {idx, t};
     }
 };
