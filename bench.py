@@ -123,11 +123,19 @@ def main():
         tests_per_launch = sum(tests) / len(tests)
         achieved_tflops = tests_per_launch * FLOP_PER_TEST / k_s / 1e12
         alg_bytes = W * H * 3 * 4 / world + n_spheres * 48        # framebuffer write + one scene read
+        # HBM bytes per launch from the committed PMC passes (profiles/), valid for the default workload only
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_1080p_1000spp.json")))
+            if (W, spp, depth, world) == (1920, 1000, 50, 1):
+                traffic = tr["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roofline = {
             "bound": "valu_fp32", "kernel": "rtw::trace_kernel<float>",
             "achieved": round(achieved_tflops, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved_tflops / FP32_VALU_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
             "kernel_ms": round(k_s * 1e3, 3), "tests_per_launch": int(tests_per_launch),
             "flop_per_test": FLOP_PER_TEST, "segments_per_sample": round(all_segments / (samples_per_step * args.steps), 4),
             "note": "peak = MI355X FP32 vector peak (= dense FP32 MFMA peak); the path has no dense contraction, so no MFMA",
