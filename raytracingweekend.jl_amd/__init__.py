@@ -21,6 +21,7 @@ from .scenes import (  # noqa: F401
 )
 from .render import DeviceRenderer, render, last_stats  # noqa: F401
 from .shard import owned_pixel_mask, render_sharded  # noqa: F401
+from . import imageio  # noqa: F401
 
 __all__ = [
     "TRNG", "Xoroshiro128Plus", "reseed", "trand", "random_between",

@@ -87,3 +87,26 @@ def test_owned_pixel_mask_partition(rtw):
             tot = np.sum(masks, axis=0)
             assert np.all(tot == 1)                               # disjoint and complete
             assert masks[0].shape == (rtw.image_height(width), width)
+
+
+def test_image_writers_and_diff(rtw, tmp_path):
+    import struct
+    import zlib
+    from conftest import load_golden
+    img = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")["image"]
+    u8 = rtw.imageio.to_u8(img)
+    assert u8.dtype == np.uint8 and u8.shape == (54, 96, 3) and u8.max() == 255     # sky reaches 1.0 in blue
+    assert np.array_equal(rtw.imageio.to_u8(np.array([[[-1.0, 0.5, 2.0]]])), [[[0, 128, 255]]])
+    p = rtw.imageio.save_ppm(img, str(tmp_path / "a.ppm"))
+    assert np.array_equal(rtw.imageio.load_ppm(p), u8)
+    q = rtw.imageio.save_png(img, str(tmp_path / "a.png"))
+    data = open(q, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", data[16:24]) == (96, 54)
+    idat = data[data.index(b"IDAT") + 4:data.index(b"IEND") - 8]
+    raw = zlib.decompress(idat)
+    rows = np.frombuffer(raw, np.uint8).reshape(54, 1 + 96 * 3)
+    assert np.all(rows[:, 0] == 0) and np.array_equal(rows[:, 1:].reshape(54, 96, 3), u8)
+    r = rtw.imageio.diff_report(img, img)
+    assert r["identical"] and r["max_abs"] == 0 and r["psnr_db"] == float("inf")
+    r = rtw.imageio.diff_report(img, img + np.float32(1e-3))
+    assert not r["identical"] and abs(r["max_abs"] - 1e-3) < 1e-6 and r["frac_within_2e3"] == 1.0
