@@ -8,7 +8,6 @@
 // Every variant must return exactly the (index, t) of variant 0 (the straight restatement of
 // src/hit.jl:38-50); the harness checks that before timing means anything.
 #include <hip/hip_runtime.h>
-#include "../raytracingweekend.jl_amd/csrc/rtw_device.hpp"
 
 #include <cmath>
 #include <cstdint>
@@ -180,19 +179,6 @@ struct V5 {
     }
 };
 
-// ---- variant 7: the product's two-pass scan (rtw_device.hpp hit_world) -----------------------
-struct V7 {
-    static constexpr const char *name = "v7 PRODUCT: sign-bit mask pass + LDS list resolve";
-    static constexpr int lds_bytes = RTW_LIST_CAP * 256 * 2;
-    __device__ static Hit scan(const float4 *g, const float4 *lds_raw, int n, Ray r) {
-        rtw::DevScene<float> w{g, nullptr, nullptr, n, n};
-        unsigned short *list = (unsigned short *)lds_raw + threadIdx.x;
-        float t;
-        int idx = rtw::hit_world<float, 256>(w, g, rtw::V3<float>{r.ox, r.oy, r.oz}, rtw::V3<float>{r.dx, r.dy, r.dz}, 1e-4f, INFINITY, t, list);
-        return {idx, t};
-    }
-};
-
 // ---- variant 9: pass-1 VALU work only: sphere data stays in SGPRs, no SMEM in the loop --------
 // (upper bound for pass 1 if scalar-load latency were free; results are NOT comparable to v0)
 struct V9 {
@@ -215,6 +201,62 @@ struct V9 {
                 }
             }
             acc += __popc(mask);
+        }
+        return {(int)acc, 0.f};
+    }
+};
+
+// ---- variant 10: packed math, 2 spheres per VALU instruction ----------------------------------
+// pair layout in memory: (c0x,c1x, c0y,c1y, c0z,c1z, r2_0,r2_1) = 8 floats per sphere pair;
+// v_pk_add/mul/fma_f32 with the SGPR pair as one operand and the ray component broadcast.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct V10 {
+    static constexpr const char *name = "v10 packed: 2 spheres/instr (v_pk_*), sign-mask only";
+    static constexpr int lds_bytes = 0;
+    __device__ static Hit scan(const float4 *__restrict__ g, const float4 *, int n, Ray r) {
+        typedef const float __attribute__((address_space(4))) *cptr;
+        cptr p = (cptr)(uintptr_t)g;       // harness passes the pair-transposed array for this variant
+        const f2 ox = {r.ox, r.ox}, oy = {r.oy, r.oy}, oz = {r.oz, r.oz}, dx = {r.dx, r.dx}, dy = {r.dy, r.dy}, dz = {r.dz, r.dz};
+        unsigned acc = 0;
+        for (int base = 0; base < n; base += 32) {
+            unsigned mask = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {            // 16 pairs = 32 spheres
+                cptr s = p + (base / 2 + q) * 8;
+                const f2 cx = {s[0], s[1]}, cy = {s[2], s[3]}, cz = {s[4], s[5]}, r2 = {s[6], s[7]};
+                const f2 ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+                f2 hb = ocx * dx;
+                hb = __builtin_elementwise_fma(ocy, dy, hb);
+                hb = __builtin_elementwise_fma(ocz, dz, hb);
+                f2 nc = __builtin_elementwise_fma(-ocx, ocx, r2);
+                nc = __builtin_elementwise_fma(-ocy, ocy, nc);
+                nc = __builtin_elementwise_fma(-ocz, ocz, nc);
+                const f2 disc = __builtin_elementwise_fma(hb, hb, nc);
+                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(disc.x), 31);
+                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(disc.y), 31);
+            }
+            acc += __popc(~mask);
+        }
+        return {(int)acc, 0.f};
+    }
+};
+// ---- variant 11: v4-like scalar (non-packed) sign-mask only, for an apples-to-apples baseline --
+struct V11 {
+    static constexpr const char *name = "v11 scalar-load scalar-math, sign-mask only";
+    static constexpr int lds_bytes = 0;
+    __device__ static Hit scan(const float4 *__restrict__ g, const float4 *, int n, Ray r) {
+        typedef const float __attribute__((address_space(4))) *cptr;
+        cptr p = (cptr)(uintptr_t)g;
+        unsigned acc = 0;
+        for (int base = 0; base < n; base += 32) {
+            unsigned mask = 0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                cptr s = p + (base + k) * 4;
+                float hb, dc; disc_of(float4{s[0], s[1], s[2], s[3]}, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, hb, dc);
+                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(dc), 31);
+            }
+            acc += __popc(~mask);
         }
         return {(int)acc, 0.f};
     }
@@ -339,6 +381,15 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&d_g, (n + 8) * sizeof(float4))); CHECK(hipMalloc(&d_r, nrays * sizeof(Ray)));
     CHECK(hipMalloc(&d_o0, lanes * sizeof(Hit))); CHECK(hipMalloc(&d_o, lanes * sizeof(Hit)));
     CHECK(hipMemcpy(d_g, g.data(), (n + 8) * sizeof(float4), hipMemcpyHostToDevice));
+    // pair-transposed copy for the packed variant
+    std::vector<float> gp((n + 8) * 4);
+    for (int q = 0; q < (n + 8) / 2; ++q) {
+        const float4 a = g[2 * q], b = g[2 * q + 1];
+        float *o = &gp[q * 8];
+        o[0] = a.x; o[1] = b.x; o[2] = a.y; o[3] = b.y; o[4] = a.z; o[5] = b.z; o[6] = a.w; o[7] = b.w;
+    }
+    float4 *d_gp; CHECK(hipMalloc(&d_gp, (n + 8) * sizeof(float4)));
+    CHECK(hipMemcpy(d_gp, gp.data(), (n + 8) * sizeof(float4), hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<Hit> h0(lanes), h(lanes);
     printf("%d spheres (%d padded), %d lanes x %d rays\n", n_real, n, lanes, rays_per_lane);
@@ -362,7 +413,11 @@ int main(int argc, char **argv) {
         run([&](Hit *dst) { hipLaunchKernelGGL(scan_kernel<V>, dim3(blocks), dim3(threads), V::lds_bytes, 0, d_g, n, d_r, rays_per_lane, dst); }, V::name, ISREF ? d_o0 : d_o, sname); \
         if (!ISREF) { CHECK(hipMemcpy(h.data(), d_o, lanes * sizeof(Hit), hipMemcpyDeviceToHost)); size_t bad = 0; for (int i = 0; i < lanes; ++i) bad += (h[i].idx != h0[i].idx || h[i].t != h0[i].t); if (bad) printf("      MISMATCH vs v0 on %zu lanes\n", bad); } \
         else { CHECK(hipMemcpy(h0.data(), d_o0, lanes * sizeof(Hit), hipMemcpyDeviceToHost)); long hits = 0; for (int i = 0; i < lanes; ++i) hits += h0[i].idx; printf("      (checksum %ld)\n", hits); }
-        RUNV(V0, true) RUNV(V1, false) RUNV(V2, false) RUNV(V3, false) RUNV(V4, false) RUNV(V5, false) RUNV(V7, false) RUNV(V9, false)
+        RUNV(V0, true) RUNV(V1, false) RUNV(V2, false) RUNV(V3, false) RUNV(V4, false) RUNV(V5, false) RUNV(V9, false) RUNV(V11, false)
+        run([&](Hit *dst) { hipLaunchKernelGGL(scan_kernel<V10>, dim3(blocks), dim3(threads), 0, 0, d_gp, n, d_r, rays_per_lane, dst); }, V10::name, d_o, sname);
+        { std::vector<Hit> h11(lanes); CHECK(hipMemcpy(h11.data(), d_o, lanes * sizeof(Hit), hipMemcpyDeviceToHost));
+          hipLaunchKernelGGL(scan_kernel<V11>, dim3(blocks), dim3(threads), 0, 0, d_g, n, d_r, rays_per_lane, d_o); CHECK(hipMemcpy(h.data(), d_o, lanes * sizeof(Hit), hipMemcpyDeviceToHost));
+          size_t bad = 0; for (int i = 0; i < lanes; ++i) bad += (h[i].idx != h11[i].idx); printf("      v10 vs v11 candidate counts: %zu lanes differ\n", bad); }
         run([&](Hit *dst) { hipLaunchKernelGGL(scan2_kernel, dim3(blocks), dim3(threads), 0, 0, d_g, n, d_r, rays_per_lane, dst); }, "v6 scalar-load, 2 rays/lane, 4 spheres/iter", d_o, sname);
         CHECK(hipMemcpy(h.data(), d_o, lanes * sizeof(Hit), hipMemcpyDeviceToHost));
         { size_t bad = 0; for (int i = 0; i < lanes; ++i) bad += (h[i].idx != h0[i].idx); if (bad) printf("      MISMATCH(idx sum) vs v0 on %zu lanes\n", bad); }
