@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunks", type=int, default=0, help="sample chunks per pixel (0 = library default rule)")
+    ap.add_argument("--emulate-shard-of", type=int, default=0,
+                    help="analysis only: on ONE GPU render shard 0 of N (what each rank of an N-GPU run does)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
     args = ap.parse_args()
 
@@ -77,16 +80,19 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     kernel_ms, total_ms, tests, segments = [], [], [], []
+    stats_chunks = [0]
 
     def step(record):
         def shard(idx, cnt):
-            renderer.render_into(fb.data_ptr(), W, spp, depth=depth, seed=1, shard_index=idx, shard_count=cnt,
-                                 stream=stream.cuda_stream)
+            if args.emulate_shard_of > 1:
+                idx, cnt = 0, args.emulate_shard_of
+            renderer.render_into(fb.data_ptr(), W, spp, depth=depth, seed=1, n_chunks=args.chunks, shard_index=idx,
+                                 shard_count=cnt, stream=stream.cuda_stream)
             return fb
         R.render_sharded(shard, W)                          # renders this rank's tiles, one reduce onto rank 0
         if record:
             st = renderer.stats()                           # waits for this rank's kernels (HIP events on `stream`)
-            kernel_ms.append(st["kernel_ms"]); total_ms.append(st["total_ms"])
+            kernel_ms.append(st["kernel_ms"]); total_ms.append(st["total_ms"]); stats_chunks[0] = st["n_chunks"]
             tests.append(st["sphere_tests"]); segments.append(st["segments"])
 
     def fence():
@@ -158,6 +164,9 @@ def main():
             cpu = {"value": round(W * H * s_spp / tc / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
                    "sample": f"same scene/camera/{W}x{H}/depth {depth}, {s_spp} spp ({tc:.1f} s), oracle/ C port with OpenMP; "
                              f"the Julia reference cannot run here (no julia in the image)"}
+        if args.emulate_shard_of > 1:
+            samples_per_step = samples_per_step / args.emulate_shard_of
+            value = samples_per_step * args.steps / dt / 1e6
         line = {
             "metric": "Msamples/s (pixels x spp) on scene_random_spheres 1920x1080",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -166,7 +175,7 @@ def main():
             "config": {"workload": f"scene_random_spheres ({n_spheres} spheres, reseed!() seed 1), t_cam1, {W}x{H}, {spp} spp, "
                                    f"depth {depth}, Float32 (BASELINE.json configs[2])",
                        "parallelism": f"tile-sharded x{world}" + (" + 1 RCCL reduce" if world > 1 else ""),
-                       "rng": "Xoroshiro128+ per (pixel, chunk), 16 chunks/pixel"},
+                       "rng": f"Xoroshiro128+ per (pixel, chunk), {stats_chunks[0]} chunks/pixel"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if cpu:

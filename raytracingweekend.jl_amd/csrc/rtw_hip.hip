@@ -154,7 +154,7 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
     if (p->flags != 0) return fail(-2, "flags must be 0");
-    int nch = p->n_chunks > 0 ? p->n_chunks : (p->spp < 16 ? p->spp : 16);
+    int nch = p->n_chunks > 0 ? p->n_chunks : (p->spp < 128 ? p->spp : 128);
     if (nch > p->spp) nch = p->spp;
     int cs = (p->spp + nch - 1) / nch;
     *chunk_spp = cs;

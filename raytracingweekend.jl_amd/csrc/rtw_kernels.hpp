@@ -55,7 +55,9 @@ __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi
 #endif
 template <typename T> struct TraceWaves { static constexpr int value = RTW_TRACE_WAVES_F32; };
 template <> struct TraceWaves<double> { static constexpr int value = 4; };
+#ifndef RTW_ITEM_BATCH
 #define RTW_ITEM_BATCH 64u   // work items a wave takes from the global queue per atomic
+#endif
 
 template <typename T, bool PROFILE, bool LDS_SCENE>
 __global__ __launch_bounds__(256, TraceWaves<T>::value) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,

@@ -48,13 +48,13 @@ def test_image_matches_golden_bit_exact(name):
 
 def test_default_chunk_rule_matches_oracle(oracle):
     g = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
-    for spp in (1, 5, 16, 40):
+    for spp in (1, 5, 16, 40, 300):
         img, st = gpu_render(g, spp=spp, n_chunks=0)
         ref, ost = oracle.render(g["flat"], g["cam"], g["width"], g["height"], spp, T=np.float32,
                                  max_depth=g["depth"], seed=g["seed"], n_chunks=oracle.default_n_chunks(spp))
         assert np.array_equal(img, ref) and st.segments == ost["segments"], spp
-        cs = -(-spp // min(spp, 16))
-        assert st.n_chunks == -(-spp // cs)            # non-empty chunks of ceil(spp/16) samples
+        cs = -(-spp // min(spp, 128))
+        assert st.n_chunks == -(-spp // cs)            # non-empty chunks of ceil(spp/128) samples
 
 
 def test_ragged_sizes_and_edge_tiles(oracle):
@@ -179,3 +179,35 @@ def test_full_size_properties(oracle, rtw):
     assert np.array_equal(a + b, img)
     # the picture is the right picture: sky gradient on top, three big spheres, grey ground
     assert img[:200].mean() > 0.7 and 0.2 < img[900:, :, :].mean() < 0.8
+
+
+def test_large_scene_global_gather_path(oracle):
+    """2 000 spheres: geom no longer fits the LDS staging budget, pass 2 gathers from global memory"""
+    rng = np.random.default_rng(7)
+    n = 2000
+    T = np.float32
+    flat = dict(n=n, cx=rng.uniform(-8, 8, n).astype(T), cy=rng.uniform(-3, 3, n).astype(T),
+                cz=rng.uniform(-12, -2, n).astype(T), r=rng.uniform(0.05, 0.3, n).astype(T),
+                kind=rng.integers(0, 3, n).astype(np.int32), ar=rng.uniform(0, 1, n).astype(T),
+                ag=rng.uniform(0, 1, n).astype(T), ab=rng.uniform(0, 1, n).astype(T),
+                param=np.zeros(n, T))
+    flat["param"][flat["kind"] == 1] = rng.uniform(0, 1, int((flat["kind"] == 1).sum())).astype(T)
+    flat["param"][flat["kind"] == 2] = T(1.5)
+    g = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
+    g = dict(g, flat=flat)
+    img, st = gpu_render(g, width=64, height=36, spp=3, n_chunks=3, max_depth=8)
+    ref, ost = oracle.render(flat, g["cam"], 64, 36, 3, T=T, max_depth=8, seed=g["seed"], n_chunks=3)
+    assert np.array_equal(img, ref) and st.segments == ost["segments"]
+    assert st.sphere_tests == ost["segments"] * n
+
+
+def test_too_many_spheres_is_an_error():
+    import ctypes as C
+    from rtw_amd import _capi
+    n = 70000
+    z = np.zeros(n, np.float32)
+    flat = dict(n=n, cx=z, cy=z, cz=z, r=z + 1, kind=np.zeros(n, np.int32), ar=z, ag=z, ab=z, param=z)
+    S, keep = _capi.make_scene(flat, np.float32)
+    h = C.c_void_p()
+    rc = _capi.lib().rtw_scene_upload_f32(C.byref(S), 0, C.byref(h))
+    assert rc == -5 and b"too many spheres" in _capi.lib().rtw_last_error()
