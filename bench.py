@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--group-cull", action="store_true", help="time the opt-in accelerated scan instead of the plain one")
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per pixel (0 = library default rule)")
     ap.add_argument("--emulate-shard-of", type=int, default=0,
                     help="analysis only: on ONE GPU render shard 0 of N (what each rank of an N-GPU run does)")
@@ -87,7 +88,7 @@ def main():
             if args.emulate_shard_of > 1:
                 idx, cnt = 0, args.emulate_shard_of
             renderer.render_into(fb.data_ptr(), W, spp, depth=depth, seed=1, n_chunks=args.chunks, shard_index=idx,
-                                 shard_count=cnt, stream=stream.cuda_stream)
+                                 shard_count=cnt, stream=stream.cuda_stream, group_cull=args.group_cull)
             return fb
         R.render_sharded(shard, W)                          # renders this rank's tiles, one reduce onto rank 0
         if record:

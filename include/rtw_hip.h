@@ -57,6 +57,11 @@ typedef struct {
     double lens_radius;
 } rtw_camera_f64;
 
+/* rtw_params.flags.  RTW_FLAG_GROUP_CULL: opt-in accelerated closest-hit scan:
+ * spheres are clustered at upload and clusters whose inflated bounding sphere a ray provably
+ * misses are skipped.  Bit-identical images; default (0) is the reference's plain linear scan. */
+#define RTW_FLAG_GROUP_CULL 1
+
 /* Positional arguments of render() plus the keyword extras of the shim. */
 typedef struct {
     int32_t width;        /* image_width  (src/render.jl:8)                                   */
@@ -70,7 +75,7 @@ typedef struct {
     int32_t shard_count;  /*   t mod shard_count == shard_index; other pixels are written 0    */
     int32_t device;       /* HIP device ordinal; -1 = current device                          */
     int32_t gamma;        /* 1 = sqrt per channel (rgb_gamma2, src/vec.jl:22); 0 = linear mean */
-    int32_t flags;        /* reserved, must be 0                                              */
+    int32_t flags;        /* 0, or RTW_FLAG_* (opt-in modes; the image is identical in every mode)    */
 } rtw_params;
 
 /* Counters of the most recent render on the calling thread's device context. */

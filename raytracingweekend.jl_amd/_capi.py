@@ -116,7 +116,10 @@ def make_camera(cam, T):
     return Cm
 
 
+FLAG_GROUP_CULL = 1   # include/rtw_hip.h RTW_FLAG_GROUP_CULL
+
+
 def make_params(width, height, spp, max_depth=16, seed=1, n_chunks=0, shard_index=0, shard_count=1,
-                device=-1, gamma=1):
+                device=-1, gamma=1, flags=0):
     return Params(int(width), int(height), int(spp), int(max_depth), int(seed), int(n_chunks),
-                  int(shard_index), int(shard_count), int(device), int(gamma), 0)
+                  int(shard_index), int(shard_count), int(device), int(gamma), int(flags))

@@ -352,6 +352,161 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
     return idx;
 }
 
+// ==== opt-in accelerated scan (rtw_params.flags & RTW_FLAG_GROUP_CULL) ===========================
+// a clearly separate mode.  Results are bit-identical to the plain
+// scan; only spheres that provably cannot be hit are skipped.
+//   * At upload the spheres are split into a BIG class (tested exactly by every lane, e.g. the
+//     r = 1000 ground) and clusters of RTW_CULL_GS small spheres (kd median split) with a
+//     bounding sphere each.  Device order: cluster-major, then the big class.
+//   * level 1 (wave-uniform, SGPR data, same code shape as pass 1): every lane tests every
+//     cluster's bounding sphere, radius inflated per ray by
+//         m = kappa * (|o - Cs| + Rs + 1),   kappa = 2^-8 (Float32) / 2^-22 (Float64),
+//     which dominates the rounding error of BOTH float evaluations: the contract discriminant
+//     of a member sphere is >= 0 only if the line passes within r_i + 4.5 sqrt(u) (|o-c_i| + r_i)
+//     of c_i (|disc_c - D| <= 20u (|o-c_i| + r_i)^2), hence within R + 4.5 sqrt(u) rho_max of
+//     the cluster centre, and the bound's own float discriminant is >= 0 whenever
+//     R' >= that + 4.5 sqrt(u) (rho_max + R'); 9 sqrt(u) = 2.2e-3 < kappa.  (Cs, Rs bound the
+//     small class; rho_max <= |o - Cs| + Rs.)
+//   * level 2 (per lane): the members of every touched cluster are tested with the contract
+//     discriminant (sphere data gathered from LDS) and the candidates pushed to the lane's list.
+//   * pass 2 is the same resolve, with the order-free acceptance rule: the reference's scan
+//     returns the minimum over the spheres of their smallest root in [tmin, inf) and the LAST
+//     sphere of the caller's list among exact ties, so a candidate is taken if root < closest,
+//     or root == closest and it comes later in the caller's list (orig[]).
+#define RTW_CULL_GS 4
+template <typename T> struct CullScene {
+    const typename Vec4<T>::type *bound;   // (Cx, Cy, Cz, R) per cluster, padded like geom (+ tail group)
+    const typename Vec4<T>::type *exact;   // (cx, cy, cz, r*r), cluster-major then big class
+    const unsigned short *orig;            // index in the caller's list
+    const typename Vec4<T>::type *mat0;    // device order
+    const typename Vec4<T>::type *mat1;
+    int n_groups_pad;                      // multiple of 2*ScanGroup<T>::N
+    int n_big;                             // device indices n_groups_pad*GS .. +n_big-1
+    T cs[3], rs;                           // bounding sphere of the small class
+    T kappa;
+};
+template <typename T> __host__ __device__ inline int cull_exact_count(const CullScene<T> &c) { return c.n_groups_pad * RTW_CULL_GS + c.n_big; }
+
+template <typename T, int STRIDE, typename SRC, typename ORIG>
+__device__ __forceinline__ void resolve_candidates_anyorder(SRC src, ORIG orig, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
+                                                            const unsigned short *list, int cnt) {
+    using V4 = typename Vec4<T>::type;
+    int i_next = cnt > 0 ? (int)list[0] : 0;
+    V4 s_next = src[i_next];
+    for (int c = 0; __any(c < cnt); ++c) {
+        const int i = i_next;
+        const V4 s = s_next;
+        i_next = (c + 1 < cnt) ? (int)list[(c + 1) * STRIDE] : 0;
+        s_next = src[i_next];
+        if (c < cnt) {
+            T hb, disc, root;
+            sphere_disc<T>(s.x, s.y, s.z, s.w, o, d, hb, disc);
+            if (sphere_root<T>(hb, disc, tmin, closest, root)) {       // root in [tmin, closest]
+                bool take = true;
+                if (root == closest && idx >= 0) take = orig[i] > orig[idx];
+                if (take) { closest = root; idx = i; }
+            }
+        }
+    }
+}
+
+template <typename T, int STRIDE, typename SRC, typename ORIG>
+__device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, ORIG orig, V3<T> o, V3<T> d, T tmin, T tmax,
+                                              T &t_hit, unsigned short *list) {
+    using V4 = typename Vec4<T>::type;
+    constexpr int G = ScanGroup<T>::N;
+    constexpr int GS = RTW_CULL_GS;
+    typedef const T __attribute__((address_space(4))) *cptr;
+    cptr gb = (cptr)(uintptr_t)w.bound;
+    cptr gx = (cptr)(uintptr_t)w.exact;
+    auto ldg = [](cptr p, int k) -> V4 { return V4{p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]}; };
+    T closest = tmax;
+    int idx = -1, cnt = 0;
+    auto push = [&](int i) {                       // lane-local: may run in divergent code
+        if (cnt >= RTW_LIST_CAP) {
+            resolve_candidates_anyorder<T, STRIDE>(src, orig, o, d, tmin, closest, idx, list, cnt);
+            cnt = 0;
+        }
+        list[cnt * STRIDE] = (unsigned short)i;
+        cnt += 1;
+    };
+
+    // big class: contract discriminant for every lane (wave-uniform sphere data)
+    const int big0 = w.n_groups_pad * GS;
+    for (int b = 0; b < w.n_big; ++b) {
+        const int i = big0 + b;
+        T hb, disc;
+        sphere_disc<T>(gx[4 * i], gx[4 * i + 1], gx[4 * i + 2], gx[4 * i + 3], o, d, hb, disc);
+        if (!(disc < T(0))) push(i);
+    }
+
+    // per-ray inflation of the cluster radii
+    const V3<T> ocs = {o.x - w.cs[0], o.y - w.cs[1], o.z - w.cs[2]};
+    const T margin = w.kappa * ((t_sqrt(dot(ocs, ocs)) + w.rs) + T(1));
+
+    V4 A[G], B[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) A[k] = ldg(gb, k);
+    cptr pw = gb;
+    auto test1 = [&](const V4 &sp, uint32_t &mask) {        // one cluster bound: 13 VALU ops
+        const T rm = sp.w + margin;
+        T hb, disc;
+        sphere_disc<T>(sp.x, sp.y, sp.z, rm * rm, o, d, hb, disc);
+        mask = __builtin_amdgcn_alignbit(mask, sign_word(disc), 31);
+    };
+    for (int base = 0; base < w.n_groups_pad; base += RTW_SPHERE_WORD) {
+        uint32_t mask = 0;
+        const int left = w.n_groups_pad - base;
+        const int npairs = left >= RTW_SPHERE_WORD ? RTW_SPHERE_WORD / (2 * G) : left / (2 * G);
+        for (int q = 0; q < npairs; ++q, pw += 2 * G * 4) {
+            test1(A[0], mask);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < G; ++k) B[k] = ldg(pw, G + k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 1; k < G; ++k) test1(A[k], mask);
+            __builtin_amdgcn_sched_barrier(0);
+            test1(B[0], mask);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < G; ++k) A[k] = ldg(pw, 2 * G + k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 1; k < G; ++k) test1(B[k], mask);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t m = ~mask;                       // bit 31 = cluster `base`
+        if (left < RTW_SPHERE_WORD) m <<= (RTW_SPHERE_WORD - npairs * 2 * G);
+        // level 2: each lane expands the clusters its ray can touch
+        while (__any(m != 0u)) {
+            if (m != 0u) {
+                const int b = __clz((int)m);
+                m &= ~(0x80000000u >> b);
+                const int first = (base + b) * GS;
+                V4 sp[GS];
+#pragma unroll
+                for (int j = 0; j < GS; ++j) sp[j] = src[first + j];
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    T hb, disc;
+                    sphere_disc<T>(sp[j].x, sp[j].y, sp[j].z, sp[j].w, o, d, hb, disc);
+                    if (!(disc < T(0))) push(first + j);
+                }
+            }
+        }
+    }
+    resolve_candidates_anyorder<T, STRIDE>(src, orig, o, d, tmin, closest, idx, list, cnt);
+    t_hit = closest;
+    return idx;
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_cull_scene(const CullScene<T> &w, typename Vec4<T>::type *dst, unsigned short *dst_orig) {
+    const int n = cull_exact_count(w);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { dst[i] = w.exact[i]; dst_orig[i] = w.orig[i]; }
+}
+
 // Stage the scene's geom array into LDS (all threads of the block; caller synchronises).
 template <typename T>
 __device__ __forceinline__ void stage_scene(const DevScene<T> &w, typename Vec4<T>::type *dst) {

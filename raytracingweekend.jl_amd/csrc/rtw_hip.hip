@@ -94,9 +94,123 @@ struct rtw_scene_dev {
     int is_f64;
     int n, n_pad;
     void *geom, *mat0, *mat1;
+    // opt-in group-cull mode (RTW_FLAG_GROUP_CULL): cluster-major copies
+    void *c_bound, *c_exact, *c_mat0, *c_mat1;
+    unsigned short *c_orig;
+    int c_groups_pad, c_big;
+    double c_cs[3], c_rs;
 };
 
 namespace {
+
+// kd median split of the small class into clusters of <= RTW_CULL_GS spheres (ids = indices into the caller's list)
+template <typename SceneT>
+void kd_split(const SceneT *s, std::vector<int> &ids, int lo, int hi, std::vector<std::vector<int>> &groups) {
+    const int cnt = hi - lo;
+    if (cnt <= RTW_CULL_GS) {
+        if (cnt > 0) groups.emplace_back(ids.begin() + lo, ids.begin() + hi);
+        return;
+    }
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int k = lo; k < hi; ++k) {
+        const double c[3] = {(double)s->cx[ids[k]], (double)s->cy[ids[k]], (double)s->cz[ids[k]]};
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], c[a]); mx[a] = std::max(mx[a], c[a]); }
+    }
+    int ax = 0;
+    for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
+    int half = ((cnt / 2 + RTW_CULL_GS - 1) / RTW_CULL_GS) * RTW_CULL_GS;      // left part: whole clusters
+    if (half >= cnt) half = cnt - 1;
+    auto key = [&](int i) { return ax == 0 ? (double)s->cx[i] : ax == 1 ? (double)s->cy[i] : (double)s->cz[i]; };
+    std::nth_element(ids.begin() + lo, ids.begin() + lo + half, ids.begin() + hi, [&](int a, int b) { return key(a) < key(b); });
+    kd_split(s, ids, lo, lo + half, groups);
+    kd_split(s, ids, lo + half, hi, groups);
+}
+
+// cluster-major arrays for the opt-in group-cull scan (rtw_device.hpp, "opt-in accelerated scan")
+template <typename T, typename SceneT>
+int build_cull(const SceneT *s, rtw_scene_dev *h) {
+    using V4 = typename rtw::Vec4<T>::type;
+    const int n = s->n;
+    constexpr int pair = 2 * rtw::ScanGroup<T>::N, GS = RTW_CULL_GS;
+    // BIG class: |r| > 4 x lower-median |r| (the ground sphere, the unit spheres of scene_random_spheres)
+    std::vector<int> small_ids, big_ids;
+    if (n > 0) {
+        std::vector<double> rr(n);
+        for (int i = 0; i < n; ++i) rr[i] = std::fabs((double)s->r[i]);
+        std::vector<double> tmp(rr);
+        std::nth_element(tmp.begin(), tmp.begin() + (n - 1) / 2, tmp.end());
+        const double thr = 4.0 * tmp[(n - 1) / 2];
+        for (int i = 0; i < n; ++i) (rr[i] > thr ? big_ids : small_ids).push_back(i);
+    }
+    std::vector<std::vector<int>> groups;
+    kd_split(s, small_ids, 0, (int)small_ids.size(), groups);
+    const int ng = (int)groups.size();
+    const int ng_pad = ((ng + pair - 1) / pair) * pair;
+    const int n_big = (int)big_ids.size();
+    const int n_exact = ng_pad * GS + n_big;
+    if (n_exact >= 65536) return fail(-5, "too many spheres (%d) for the group-cull layout", n);
+    std::vector<V4> bound(ng_pad + RTW_SPHERE_TAIL), exact(std::max(n_exact, 1)), mat0(std::max(n_exact, 1)), mat1(std::max(n_exact, 1));
+    std::vector<unsigned short> orig(std::max(n_exact, 1), 0);
+    // dead cluster: far away and empty; dead sphere: r^2 = -1e30 (never a candidate)
+    for (auto &b : bound) b = V4{(T)1e15, (T)1e15, (T)1e15, (T)0};
+    for (int k = 0; k < n_exact; ++k) { exact[k] = V4{(T)0, (T)0, (T)0, (T)-1e30}; mat0[k] = V4{(T)1, (T)0, (T)0, (T)0}; mat1[k] = V4{(T)0, (T)0, (T)0, (T)0}; }
+    auto put = [&](int k, int i) {
+        exact[k] = V4{s->cx[i], s->cy[i], s->cz[i], s->r[i] * s->r[i]};
+        mat0[k] = V4{s->r[i], s->param[i], (T)s->kind[i], (T)0};
+        mat1[k] = V4{s->ar[i], s->ag[i], s->ab[i], (T)0};
+        orig[k] = (unsigned short)i;
+    };
+    double cs[3] = {0, 0, 0}, rs = 0;
+    long nsm = 0;
+    for (auto &g : groups) for (int i : g) { cs[0] += s->cx[i]; cs[1] += s->cy[i]; cs[2] += s->cz[i]; ++nsm; }
+    if (nsm) { cs[0] /= nsm; cs[1] /= nsm; cs[2] /= nsm; }
+    for (int gi = 0; gi < ng; ++gi) {
+        const auto &g = groups[gi];
+        double c[3] = {0, 0, 0};
+        for (int i : g) { c[0] += s->cx[i]; c[1] += s->cy[i]; c[2] += s->cz[i]; }
+        for (int a = 0; a < 3; ++a) c[a] /= (double)g.size();
+        const T cT[3] = {(T)c[0], (T)c[1], (T)c[2]};                     // the ROUNDED centre is the bound's centre
+        double R = 0;
+        for (int j = 0; j < (int)g.size(); ++j) {
+            const int i = g[j];
+            const double dx = (double)s->cx[i] - cT[0], dy = (double)s->cy[i] - cT[1], dz = (double)s->cz[i] - cT[2];
+            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)s->r[i]));
+            put(gi * GS + j, i);
+            const double ex = (double)s->cx[i] - cs[0], ey = (double)s->cy[i] - cs[1], ez = (double)s->cz[i] - cs[2];
+            rs = std::max(rs, std::sqrt(ex * ex + ey * ey + ez * ez) + std::fabs((double)s->r[i]));
+        }
+        bound[gi] = V4{cT[0], cT[1], cT[2], (T)(R * (1.0 + 1e-5) + 1e-30)};
+        if ((double)bound[gi].w < R) bound[gi].w = std::nextafter(bound[gi].w, (T)INFINITY);
+    }
+    for (int k = 0; k < n_big; ++k) put(ng_pad * GS + k, big_ids[k]);
+    h->c_groups_pad = ng_pad; h->c_big = n_big;
+    h->c_cs[0] = (double)(T)cs[0]; h->c_cs[1] = (double)(T)cs[1]; h->c_cs[2] = (double)(T)cs[2];
+    h->c_rs = rs * (1.0 + 1e-5) + 1e-3 * (std::fabs(cs[0]) + std::fabs(cs[1]) + std::fabs(cs[2])) * (sizeof(T) == 4 ? 1e-4 : 1e-12);
+    const size_t bb = sizeof(V4) * bound.size(), eb = sizeof(V4) * exact.size(), ob = sizeof(unsigned short) * orig.size();
+    HIP_TRY(hipMalloc(&h->c_bound, bb));
+    HIP_TRY(hipMalloc(&h->c_exact, eb));
+    HIP_TRY(hipMalloc(&h->c_mat0, eb));
+    HIP_TRY(hipMalloc(&h->c_mat1, eb));
+    HIP_TRY(hipMalloc((void **)&h->c_orig, ob));
+    HIP_TRY(hipMemcpy(h->c_bound, bound.data(), bb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->c_exact, exact.data(), eb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->c_mat0, mat0.data(), eb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->c_mat1, mat1.data(), eb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->c_orig, orig.data(), ob, hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <typename T>
+rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
+    using V4 = typename rtw::Vec4<T>::type;
+    rtw::CullScene<T> C;
+    C.bound = (const V4 *)h->c_bound; C.exact = (const V4 *)h->c_exact; C.orig = h->c_orig;
+    C.mat0 = (const V4 *)h->c_mat0; C.mat1 = (const V4 *)h->c_mat1;
+    C.n_groups_pad = h->c_groups_pad; C.n_big = h->c_big;
+    C.cs[0] = (T)h->c_cs[0]; C.cs[1] = (T)h->c_cs[1]; C.cs[2] = (T)h->c_cs[2]; C.rs = (T)h->c_rs;
+    C.kappa = sizeof(T) == 4 ? (T)0.00390625 : (T)2.384185791015625e-07;     // 2^-8 / 2^-22
+    return C;
+}
 
 template <typename T, typename SceneT>
 int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
@@ -134,6 +248,7 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     rtw_scene_dev *h = new rtw_scene_dev();
     h->device = dev; h->is_f64 = sizeof(T) == 8; h->n = n; h->n_pad = n_pad;
     h->geom = h->mat0 = h->mat1 = nullptr;
+    h->c_bound = h->c_exact = h->c_mat0 = h->c_mat1 = nullptr; h->c_orig = nullptr;
     const size_t bytes = sizeof(V4) * (size_t)n_alloc;
     HIP_TRY(hipMalloc(&h->geom, bytes));
     HIP_TRY(hipMalloc(&h->mat0, bytes));
@@ -141,6 +256,7 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     HIP_TRY(hipMemcpy(h->geom, geom.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->mat0, mat0.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->mat1, mat1.data(), bytes, hipMemcpyHostToDevice));
+    if (int rc = build_cull<T>(s, h)) { rtw_scene_free(h); return rc; }
     *out = h;
     return 0;
 }
@@ -153,7 +269,7 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
-    if (p->flags != 0) return fail(-2, "flags must be 0");
+    if (p->flags & ~RTW_FLAG_GROUP_CULL) return fail(-2, "unknown flags 0x%x", p->flags);
     int nch = p->n_chunks > 0 ? p->n_chunks : (p->spp < 128 ? p->spp : 128);
     if (nch > p->spp) nch = p->spp;
     int cs = (p->spp + nch - 1) / nch;
@@ -208,12 +324,18 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     // persistent grid: enough 256-thread blocks to fill every CU at the kernel's occupancy
     static const bool phase_profile = getenv("RTW_PHASE_PROFILE") != nullptr;   // debugging aid, not for timed runs
     const size_t list_bytes = (size_t)RTW_LIST_CAP * 256 * sizeof(unsigned short);
-    const size_t geom_bytes = (size_t)(scene->n_pad + RTW_SPHERE_TAIL) * sizeof(V4);
+    const bool cull = (p->flags & RTW_FLAG_GROUP_CULL) != 0;
+    const rtw::CullScene<T> CS = cull_scene_of<T>(scene);
+    const size_t n_cull = (size_t)rtw::cull_exact_count(CS);
+    const size_t geom_bytes = cull ? n_cull * sizeof(V4) + ((n_cull * sizeof(unsigned short) + 15) / 16) * 16
+                                   : (size_t)(scene->n_pad + RTW_SPHERE_TAIL) * sizeof(V4);
     const bool lds_scene = geom_bytes <= RTW_LDS_SCENE_MAX_BYTES;
     const size_t lds_bytes = list_bytes + (lds_scene ? geom_bytes : 0);
-    typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, double *, rtw::DevCounters *);
-    kern_t kern = phase_profile ? (lds_scene ? (kern_t)rtw::trace_kernel<T, true, true> : (kern_t)rtw::trace_kernel<T, true, false>)
-                                : (lds_scene ? (kern_t)rtw::trace_kernel<T, false, true> : (kern_t)rtw::trace_kernel<T, false, false>);
+    typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, rtw::CullScene<T>, double *, rtw::DevCounters *);
+    kern_t kern;
+    if (cull) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true>;
+    else if (phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, false> : (kern_t)rtw::trace_kernel<T, true, false, false>;
+    else kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false> : (kern_t)rtw::trace_kernel<T, false, false, false>;
     int blocks_per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 256, lds_bytes));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -225,7 +347,7 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     HIP_TRY(hipMemsetAsync(ctx->ctr, 0, sizeof(rtw::DevCounters), stream));
     HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)p->width * p->height * 3 * sizeof(T), stream));
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, ctx->partial, ctx->ctr);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, CS, ctx->partial, ctx->ctr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
     const unsigned n_pix_local = (unsigned)n_local * 64u;
@@ -334,6 +456,11 @@ int rtw_scene_free(rtw_scene_handle h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     if (h->geom) hipFree(h->geom);
+    if (h->c_bound) hipFree(h->c_bound);
+    if (h->c_exact) hipFree(h->c_exact);
+    if (h->c_mat0) hipFree(h->c_mat0);
+    if (h->c_mat1) hipFree(h->c_mat1);
+    if (h->c_orig) hipFree(h->c_orig);
     if (h->mat0) hipFree(h->mat0);
     if (h->mat1) hipFree(h->mat1);
     delete h;

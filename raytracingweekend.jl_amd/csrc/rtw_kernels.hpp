@@ -59,17 +59,19 @@ template <> struct TraceWaves<double> { static constexpr int value = 4; };
 #define RTW_ITEM_BATCH 64u   // work items a wave takes from the global queue per atomic
 #endif
 
-template <typename T, bool PROFILE, bool LDS_SCENE>
+template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL>
 __global__ __launch_bounds__(256, TraceWaves<T>::value) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,
-                                                   double *__restrict__ partial, DevCounters *ctr) {
+                                                   CullScene<T> cull, double *__restrict__ partial, DevCounters *ctr) {
     using V4 = typename Vec4<T>::type;
     const unsigned lane = lane_id();
     // LDS: [per-lane candidate lists, stride 256][scene geom copy (LDS_SCENE only)]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short *my_list = reinterpret_cast<unsigned short *>(smem) + threadIdx.x;
     V4 *lds_geom = reinterpret_cast<V4 *>(smem + RTW_LIST_CAP * 256 * sizeof(unsigned short));
+    unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + (CULL ? cull_exact_count(cull) : 0));
     if (LDS_SCENE) {
-        stage_scene<T>(scene, lds_geom);
+        if (CULL) stage_cull_scene<T>(cull, lds_geom, lds_orig);
+        else stage_scene<T>(scene, lds_geom);
         __syncthreads();
     }
     // the wave's local pool of work items [pool_next, pool_end): one global atomic per batch
@@ -177,7 +179,12 @@ __global__ __launch_bounds__(256, TraceWaves<T>::value) void trace_kernel(KParam
         T t_hit = 0;
         int idx = -1;
         if (has_ray) {
-            if (LDS_SCENE)
+            if (CULL && LDS_SCENE)
+                idx = hit_world_cull<T, 256>(cull, (const V4 *)lds_geom, (const unsigned short *)lds_orig, ro, rd, (T)1e-4,
+                                             (T)__builtin_huge_val(), t_hit, my_list);
+            else if (CULL)
+                idx = hit_world_cull<T, 256>(cull, cull.exact, cull.orig, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list);
+            else if (LDS_SCENE)
                 idx = hit_world<T, 256>(scene, (const V4 *)lds_geom, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list, clk);
             else
                 idx = hit_world<T, 256>(scene, scene.geom, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list, clk);
@@ -192,9 +199,9 @@ __global__ __launch_bounds__(256, TraceWaves<T>::value) void trace_kernel(KParam
                 acc_r += thr_r * sky.r; acc_g += thr_g * sky.g; acc_b += thr_b * sky.b;
                 has_ray = false;
             } else {
-                const typename Vec4<T>::type g = scene.geom[idx];
-                const typename Vec4<T>::type m0 = scene.mat0[idx];
-                const typename Vec4<T>::type m1 = scene.mat1[idx];
+                const typename Vec4<T>::type g = CULL ? cull.exact[idx] : scene.geom[idx];    // CULL: device order
+                const typename Vec4<T>::type m0 = CULL ? cull.mat0[idx] : scene.mat0[idx];
+                const typename Vec4<T>::type m1 = CULL ? cull.mat1[idx] : scene.mat1[idx];
                 HitRec<T> rec;
                 make_hitrec<T>({g.x, g.y, g.z}, m0.x, ro, rd, t_hit, rec);
                 V3<T> nd, att;

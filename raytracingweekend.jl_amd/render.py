@@ -21,9 +21,11 @@ def _as_image(flat, height, width):
     return flat.reshape(width, height, 3).transpose(1, 0, 2)
 
 
-def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chunks=0, device=-1, gamma=True):
+def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chunks=0, device=-1, gamma=True,
+           group_cull=False):
     """Render ``scene`` through ``cam``; returns ``img[i, j, :]`` (row i, column j, RGB) of the
-    camera's element type, memory-identical to the reference's ``Matrix{RGB{T}}``."""
+    camera's element type, memory-identical to the reference's ``Matrix{RGB{T}}``.
+    ``group_cull=True`` selects the opt-in accelerated scan (same image, include/rtw_hip.h)."""
     global _last_stats
     if not isinstance(cam, Camera):
         raise TypeError("cam must be a Camera")
@@ -37,7 +39,8 @@ def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chun
     flat = flatten_scene(scene, T)
     S, keep = _capi.make_scene(flat, T)
     Cm = _capi.make_camera(cam, T)
-    P = _capi.make_params(image_width, height, n_samples, depth, seed, n_chunks, 0, 1, device, 1 if gamma else 0)
+    P = _capi.make_params(image_width, height, n_samples, depth, seed, n_chunks, 0, 1, device, 1 if gamma else 0,
+                           _capi.FLAG_GROUP_CULL if group_cull else 0)
     out = np.empty(height * int(image_width) * 3, dtype=T)
     fn = L.rtw_render_f64 if _capi.is_f64(T) else L.rtw_render_f32
     _capi.check(fn(C.byref(S), C.byref(Cm), C.byref(P), out.ctypes.data_as(C.c_void_p)))
@@ -71,11 +74,11 @@ class DeviceRenderer:
         del keep
 
     def render_into(self, d_out_ptr, image_width, n_samples, *, depth=16, seed=1, n_chunks=0,
-                    shard_index=0, shard_count=1, stream=0, gamma=True):
+                    shard_index=0, shard_count=1, stream=0, gamma=True, group_cull=False):
         """Enqueue one render into device memory at ``d_out_ptr`` (H*W*3 elements)."""
         height = image_height(image_width)
         P = _capi.make_params(image_width, height, n_samples, depth, seed, n_chunks, shard_index, shard_count,
-                              -1, 1 if gamma else 0)
+                              -1, 1 if gamma else 0, _capi.FLAG_GROUP_CULL if group_cull else 0)
         fn = self.L.rtw_render_device_f64 if _capi.is_f64(self.T) else self.L.rtw_render_device_f32
         _capi.check(fn(self.handle, C.byref(self.cam), C.byref(P), C.c_void_p(int(d_out_ptr)),
                        C.c_void_p(int(stream))))

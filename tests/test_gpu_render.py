@@ -23,7 +23,7 @@ def gpu_render(g, **over):
     S, keep = _capi.make_scene(g["flat"], T)
     Cm = _capi.make_camera(CamObj(g["cam"]), T)
     kw = dict(width=g["width"], height=g["height"], spp=g["spp"], max_depth=g["depth"], seed=g["seed"],
-              n_chunks=g["n_chunks"])
+              n_chunks=g["n_chunks"], flags=0)
     kw.update(over)
     P = _capi.make_params(**kw)
     out = np.empty(kw["width"] * kw["height"] * 3, T)
@@ -211,3 +211,43 @@ def test_too_many_spheres_is_an_error():
     h = C.c_void_p()
     rc = _capi.lib().rtw_scene_upload_f32(C.byref(S), 0, C.byref(h))
     assert rc == -5 and b"too many spheres" in _capi.lib().rtw_last_error()
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_group_cull_mode_is_bit_identical(name):
+    """opt-in accelerated scan (RTW_FLAG_GROUP_CULL): same image, same segment count"""
+    g = load_golden(name)
+    img, st = gpu_render(g, flags=1)
+    assert np.array_equal(img, g["image"]) and st.segments == g["segments"]
+
+
+def test_group_cull_mode_full_size_and_shards(oracle, rtw):
+    T = np.float32
+    rtw.reseed()
+    flat = rtw.flatten_scene(rtw.scene_random_spheres(elem_type=T), T)
+    cam = rtw.t_cam1(elem_type=T)
+    g = dict(flat=flat, cam={k: getattr(cam, k) for k in oracle.CAM_FIELDS + ("lens_radius",)},
+             image=np.zeros(1, T), width=1920, height=1080, spp=2, depth=50, seed=1, n_chunks=2)
+    plain, st0 = gpu_render(g)
+    fast, st1 = gpu_render(g, flags=1)
+    assert np.array_equal(plain, fast) and st0.segments == st1.segments
+    a, _ = gpu_render(g, flags=1, shard_index=1, shard_count=3)
+    b, _ = gpu_render(g, shard_index=1, shard_count=3)
+    assert np.array_equal(a, b)
+
+
+def test_group_cull_large_and_degenerate_scenes(oracle):
+    rng = np.random.default_rng(11)
+    T = np.float32
+    g0 = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
+    for n in (1, 3, 5, 2000):
+        flat = dict(n=n, cx=rng.uniform(-4, 4, n).astype(T), cy=rng.uniform(-2, 2, n).astype(T),
+                    cz=rng.uniform(-9, -2, n).astype(T), r=(rng.uniform(0.1, 0.5, n) * rng.choice([1, -1], n)).astype(T),
+                    kind=rng.integers(0, 3, n).astype(np.int32), ar=rng.uniform(0, 1, n).astype(T),
+                    ag=rng.uniform(0, 1, n).astype(T), ab=rng.uniform(0, 1, n).astype(T), param=np.full(n, 1.5, T))
+        flat["cx"][0], flat["cy"][0], flat["cz"][0] = flat["cx"][-1], flat["cy"][-1], flat["cz"][-1]   # coincident spheres: exact ties
+        flat["r"][0] = flat["r"][-1]
+        g = dict(g0, flat=flat)
+        img, st = gpu_render(g, width=64, height=36, spp=2, n_chunks=2, max_depth=6, flags=1)
+        ref, ost = oracle.render(flat, g["cam"], 64, 36, 2, T=T, max_depth=6, seed=g["seed"], n_chunks=2)
+        assert np.array_equal(img, ref) and st.segments == ost["segments"], n
