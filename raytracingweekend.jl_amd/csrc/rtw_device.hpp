@@ -373,7 +373,9 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 //     returns the minimum over the spheres of their smallest root in [tmin, inf) and the LAST
 //     sphere of the caller's list among exact ties, so a candidate is taken if root < closest,
 //     or root == closest and it comes later in the caller's list (orig[]).
-#define RTW_CULL_GS 4
+#ifndef RTW_CULL_GS
+#define RTW_CULL_GS 8   // spheres per cluster
+#endif
 template <typename T> struct CullScene {
     const typename Vec4<T>::type *bound;   // (Cx, Cy, Cz, R) per cluster, padded like geom (+ tail group)
     const typename Vec4<T>::type *exact;   // (cx, cy, cz, r*r), cluster-major then big class
@@ -410,9 +412,9 @@ __device__ __forceinline__ void resolve_candidates_anyorder(SRC src, ORIG orig, 
     }
 }
 
-template <typename T, int STRIDE, typename SRC, typename ORIG>
+template <typename T, int STRIDE, typename SRC, typename ORIG, typename CLK = NoClock>
 __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, ORIG orig, V3<T> o, V3<T> d, T tmin, T tmax,
-                                              T &t_hit, unsigned short *list) {
+                                              T &t_hit, unsigned short *list, CLK &&clk = NoClock()) {
     using V4 = typename Vec4<T>::type;
     constexpr int G = ScanGroup<T>::N;
     constexpr int GS = RTW_CULL_GS;
@@ -437,7 +439,7 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
         const int i = big0 + b;
         T hb, disc;
         sphere_disc<T>(gx[4 * i], gx[4 * i + 1], gx[4 * i + 2], gx[4 * i + 3], o, d, hb, disc);
-        if (!(disc < T(0))) push(i);
+        if (!(disc < T(0))) { if (!(hb > T(0)) || disc > hb * hb) push(i); }
     }
 
     // per-ray inflation of the cluster radii
@@ -476,6 +478,7 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
             for (int k = 1; k < G; ++k) test1(B[k], mask);
             __builtin_amdgcn_sched_barrier(0);
         }
+        clk.lap(2);
         uint32_t m = ~mask;                       // bit 31 = cluster `base`
         if (left < RTW_SPHERE_WORD) m <<= (RTW_SPHERE_WORD - npairs * 2 * G);
         // level 2: each lane expands the clusters its ray can touch
@@ -491,12 +494,16 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
                 for (int j = 0; j < GS; ++j) {
                     T hb, disc;
                     sphere_disc<T>(sp[j].x, sp[j].y, sp[j].z, sp[j].w, o, d, hb, disc);
-                    if (!(disc < T(0))) push(first + j);
+                    // rare branch.  A root >= tmin > 0 needs half_b <= 0 or disc > half_b^2 (else
+                    // -half_b + sqrt(disc) <= 0): spheres entirely behind the ray are not even listed.
+                    if (!(disc < T(0))) { if (!(hb > T(0)) || disc > hb * hb) push(first + j); }
                 }
             }
         }
+        clk.lap(4);
     }
     resolve_candidates_anyorder<T, STRIDE>(src, orig, o, d, tmin, closest, idx, list, cnt);
+    clk.lap(5);
     t_hit = closest;
     return idx;
 }

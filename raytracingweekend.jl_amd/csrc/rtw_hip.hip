@@ -40,6 +40,8 @@ struct DeviceCtx {
     int device = -1;
     double *partial = nullptr;
     size_t partial_bytes = 0;
+    void *puv = nullptr;
+    size_t puv_bytes = 0;
     rtw::DevCounters *ctr = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     int num_cus = 0;
@@ -261,6 +263,16 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     return 0;
 }
 
+// magic number for exact unsigned 32-bit division by an invariant d >= 1 (Granlund-Montgomery / Hacker's
+// Delight "add" form): n / d == (umulhi(n, m) + ((n - umulhi(n, m)) >> 1)) >> s for all 32-bit n
+void make_udiv(unsigned d, unsigned *m, unsigned *s) {
+    if (d <= 1) { *m = 0; *s = 0x80000000u; return; }   // flag: identity
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;                        // l = ceil(log2 d) >= 1
+    *m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    *s = l - 1;
+}
+
 int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (!p) return fail(-1, "null params");
     if (p->width <= 0 || p->height <= 0) return fail(-2, "width/height must be positive (got %d x %d)", p->width, p->height);
@@ -301,6 +313,24 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     const long long total_items = n_local * nch * 64;
     if (total_items >= (1ll << 31)) return fail(-5, "render too large for one call: %lld work items", total_items);
     K.n_local_tiles = (int)n_local; K.total_items = (unsigned)total_items; K.gamma = p->gamma;
+    make_udiv((unsigned)nch, &K.div_chunks_m, &K.div_chunks_s);
+    make_udiv((unsigned)K.tiles_i, &K.div_tiles_m, &K.div_tiles_s);
+
+    // per-column / per-row (u, v) of src/render.jl:26-27: T(j / W) and T((H - i) / H), Float64 division
+    // then conversion, evaluated here on the host (exactly the arithmetic the reference performs)
+    {
+        std::vector<T> puv((size_t)p->width + p->height);
+        for (int j0 = 0; j0 < p->width; ++j0) puv[j0] = (T)((double)(j0 + 1) / (double)p->width);
+        for (int i0 = 0; i0 < p->height; ++i0) puv[(size_t)p->width + i0] = (T)((double)(p->height - (i0 + 1)) / (double)p->height);
+        const size_t pb = puv.size() * sizeof(T);
+        if (ctx->puv_bytes < pb) {
+            if (ctx->puv) { HIP_TRY(hipFree(ctx->puv)); ctx->puv = nullptr; ctx->puv_bytes = 0; }
+            HIP_TRY(hipMalloc(&ctx->puv, pb));
+            ctx->puv_bytes = pb;
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->puv, puv.data(), pb, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));          // puv is a stack-local host buffer
+    }
 
     const size_t need = (size_t)(total_items > 0 ? total_items : 1) * 3 * sizeof(double);
     if (ctx->partial_bytes < need) {
@@ -331,9 +361,10 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
                                    : (size_t)(scene->n_pad + RTW_SPHERE_TAIL) * sizeof(V4);
     const bool lds_scene = geom_bytes <= RTW_LDS_SCENE_MAX_BYTES;
     const size_t lds_bytes = list_bytes + (lds_scene ? geom_bytes : 0);
-    typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, rtw::CullScene<T>, double *, rtw::DevCounters *);
+    typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, rtw::CullScene<T>, const T *, double *, rtw::DevCounters *);
     kern_t kern;
-    if (cull) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true>;
+    if (cull && phase_profile) kern = (kern_t)rtw::trace_kernel<T, true, true, true>;      // profiling aid: LDS path only
+    else if (cull) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true>;
     else if (phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, false> : (kern_t)rtw::trace_kernel<T, true, false, false>;
     else kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false> : (kern_t)rtw::trace_kernel<T, false, false, false>;
     int blocks_per_cu = 0;
@@ -347,7 +378,7 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     HIP_TRY(hipMemsetAsync(ctx->ctr, 0, sizeof(rtw::DevCounters), stream));
     HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)p->width * p->height * 3 * sizeof(T), stream));
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, CS, ctx->partial, ctx->ctr);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, CS, (const T *)ctx->puv, ctx->partial, ctx->ctr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
     const unsigned n_pix_local = (unsigned)n_local * 64u;
@@ -494,7 +525,7 @@ int rtw_stats(rtw_stats_t *out) {
     if (getenv("RTW_PHASE_PROFILE")) {
         double tot = 0;
         for (int k = 0; k < 6; ++k) tot += (double)c.phase[k];
-        fprintf(stderr, "[rtw phase profile] wave-cycles: pull %.1f%%  raygen %.1f%%  scan-pass1 %.1f%%  extract %.1f%%  resolve %.1f%%  shade %.1f%%  (total %.3g)\n",
+        fprintf(stderr, "[rtw phase profile] wave-cycles: pull %.1f%%  raygen %.1f%%  scan-pass1/level1 %.1f%%  extract/level2 %.1f%%  resolve %.1f%%  shade %.1f%%  (total %.3g)\n",
                 100 * c.phase[0] / tot, 100 * c.phase[1] / tot, 100 * c.phase[2] / tot, 100 * c.phase[4] / tot,
                 100 * c.phase[5] / tot, 100 * c.phase[3] / tot, tot);
     }
@@ -522,6 +553,7 @@ int rtw_shutdown(void) {
     for (DeviceCtx *c : g_ctx) {
         hipSetDevice(c->device);
         if (c->partial) hipFree(c->partial);
+        if (c->puv) hipFree(c->puv);
         if (c->ctr) hipFree(c->ctr);
         if (c->ev0) hipEventDestroy(c->ev0);
         if (c->ev1) hipEventDestroy(c->ev1);

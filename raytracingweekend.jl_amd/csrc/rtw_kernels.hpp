@@ -26,6 +26,9 @@ struct KParams {
     int tiles_i, tiles_j;  // 8x8 tiles along rows (i) and columns (j)
     int n_local_tiles;
     unsigned total_items;  // n_local_tiles * n_chunks * 64
+    // exact unsigned division by the two loop-invariant divisors of the item decode (host: make_udiv):
+    // n / d == (umulhi(n, m) + ((n - umulhi(n, m)) >> 1)) >> s   for every 32-bit n
+    unsigned div_chunks_m, div_chunks_s, div_tiles_m, div_tiles_s;
     int gamma;
 };
 
@@ -46,6 +49,12 @@ template <bool ON> struct PhaseClock {
     }
 };
 
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned s) {
+    if (s & 0x80000000u) return n;                      // divisor 1
+    const unsigned t = __umulhi(n, m);
+    return (t + ((n - t) >> 1)) >> s;
+}
+
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // waves per SIMD the trace kernel is compiled for (second __launch_bounds__ argument):
@@ -61,7 +70,8 @@ template <> struct TraceWaves<double> { static constexpr int value = 4; };
 
 template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL>
 __global__ __launch_bounds__(256, TraceWaves<T>::value) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,
-                                                   CullScene<T> cull, double *__restrict__ partial, DevCounters *ctr) {
+                                                   CullScene<T> cull, const T *__restrict__ puv,
+                                                   double *__restrict__ partial, DevCounters *ctr) {
     using V4 = typename Vec4<T>::type;
     const unsigned lane = lane_id();
     // LDS: [per-lane candidate lists, stride 256][scene geom copy (LDS_SCENE only)]
@@ -123,17 +133,18 @@ __global__ __launch_bounds__(256, TraceWaves<T>::value) void trace_kernel(KParam
                 if (idx >= P.total_items) {
                     alive = false;
                 } else {
-                    const unsigned per_tile = (unsigned)P.n_chunks * 64u;
-                    const unsigned k = (unsigned)idx / per_tile;         // local tile
-                    const unsigned rem = (unsigned)idx % per_tile;
-                    const unsigned chunk = rem >> 6, pl = rem & 63u;
+                    // idx = (k * n_chunks + chunk) * 64 + pl
+                    const unsigned pl = (unsigned)idx & 63u, q = (unsigned)idx >> 6;
+                    const unsigned k = udiv_magic(q, P.div_chunks_m, P.div_chunks_s);      // local tile
+                    const unsigned chunk = q - k * (unsigned)P.n_chunks;
                     const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
-                    const int ti = (int)(t % (unsigned)P.tiles_i), tj = (int)(t / (unsigned)P.tiles_i);
+                    const int tj = (int)udiv_magic(t, P.div_tiles_m, P.div_tiles_s), ti = (int)(t - (unsigned)tj * (unsigned)P.tiles_i);
                     const int i0 = ti * 8 + (int)(pl & 7u), j0 = tj * 8 + (int)(pl >> 3);  // 0-based
                     if (i0 < P.height && j0 < P.width) {
                         const int i = i0 + 1, j = j0 + 1;                // Julia's 1-based (i, j)
-                        pu = (T)((double)j / (double)P.width);           // src/render.jl:26
-                        pv = (T)((double)(P.height - i) / (double)P.height);  // :27
+                        pu = puv[j0];                                    // T(j / W),       src/render.jl:26
+                        pv = puv[P.width + i0];                          // T((H - i) / H), src/render.jl:27
+                        (void)i; (void)j;
                         const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
                         rng_stream(P.seed, pix, chunk, rng);
                         s_global = (int)chunk * P.chunk_spp;
@@ -181,9 +192,9 @@ __global__ __launch_bounds__(256, TraceWaves<T>::value) void trace_kernel(KParam
         if (has_ray) {
             if (CULL && LDS_SCENE)
                 idx = hit_world_cull<T, 256>(cull, (const V4 *)lds_geom, (const unsigned short *)lds_orig, ro, rd, (T)1e-4,
-                                             (T)__builtin_huge_val(), t_hit, my_list);
+                                             (T)__builtin_huge_val(), t_hit, my_list, clk);
             else if (CULL)
-                idx = hit_world_cull<T, 256>(cull, cull.exact, cull.orig, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list);
+                idx = hit_world_cull<T, 256>(cull, cull.exact, cull.orig, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list, clk);
             else if (LDS_SCENE)
                 idx = hit_world<T, 256>(scene, (const V4 *)lds_geom, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list, clk);
             else
