@@ -144,7 +144,7 @@ def main():
             tmax = torch.tensor([dta], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dta = float(tmax.item())
-        accel = {"mode": "RTW_FLAG_GROUP_CULL (kd clusters of 8 + per-ray inflated bounding spheres; same image bit for bit)",
+        accel = {"mode": "RTW_FLAG_GROUP_CULL (kd clusters of 16 + conservative per-ray grown AABB slab test; same image bit for bit)",
                  "value": round(samples_per_step * args.steps / dta / 1e6, 2), "unit": "Msamples/s",
                  "ms_per_step": round(dta / args.steps * 1e3, 3)}
 

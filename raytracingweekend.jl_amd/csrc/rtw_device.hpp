@@ -356,38 +356,47 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 // a clearly separate mode.  Results are bit-identical to the plain
 // scan; only spheres that provably cannot be hit are skipped.
 //   * At upload the spheres are split into a BIG class (tested exactly by every lane, e.g. the
-//     r = 1000 ground) and clusters of RTW_CULL_GS small spheres (kd median split) with a
-//     bounding sphere each.  Device order: cluster-major, then the big class.
-//   * level 1 (wave-uniform, SGPR data, same code shape as pass 1): every lane tests every
-//     cluster's bounding sphere, radius inflated per ray by
-//         m = kappa * (|o - Cs| + Rs + 1),   kappa = 2^-8 (Float32) / 2^-22 (Float64),
-//     which dominates the rounding error of BOTH float evaluations: the contract discriminant
-//     of a member sphere is >= 0 only if the line passes within r_i + 4.5 sqrt(u) (|o-c_i| + r_i)
-//     of c_i (|disc_c - D| <= 20u (|o-c_i| + r_i)^2), hence within R + 4.5 sqrt(u) rho_max of
-//     the cluster centre, and the bound's own float discriminant is >= 0 whenever
-//     R' >= that + 4.5 sqrt(u) (rho_max + R'); 9 sqrt(u) = 2.2e-3 < kappa.  (Cs, Rs bound the
-//     small class; rho_max <= |o - Cs| + Rs.)
+//     r = 1000 ground) and clusters of <= RTW_CULL_GS small spheres (kd median split) with an
+//     axis-aligned bounding box each.  Device order: cluster-major, then the big class.
+//   * level 1 (wave-uniform, SGPR data, software-pipelined like pass 1): every lane runs a slab
+//     test of its RAY (t >= 0) against every cluster box, the box inflated per ray by
+//         m = kappa * (|o - Cs| + Rs + 1),   kappa = 2^-8 (Float32) / 2^-22 (Float64).
+//     Why this is conservative: sphere_root accepts sphere i only if its contract discriminant is
+//     >= 0, and |disc_c - D| <= 20u (|o-c_i| + r_i)^2, so the line passes within
+//     r_i + 4.5 sqrt(u) (|o-c_i| + r_i) <= r_i + m/2 of c_i; an accepted root is >= tmin > 0, so
+//     either the closest approach is in front of the origin (that point is inside the box grown
+//     by m/2) or the origin itself is within r_i + m/2 of c_i.  The slab arithmetic adds
+//     relative errors of a few u to parameters of size <= |o - Cs| + Rs, far below m/2
+//     (9 sqrt(u) = 2.2e-3 < kappa/2 = 1.95e-3 ... kappa covers both with the +1 term); direction
+//     components smaller than 1e-9 are replaced by +-1e-9 (moves the ray by < 1e-9 t).
 //   * level 2 (per lane): the members of every touched cluster are tested with the contract
-//     discriminant (sphere data gathered from LDS) and the candidates pushed to the lane's list.
-//   * pass 2 is the same resolve, with the order-free acceptance rule: the reference's scan
-//     returns the minimum over the spheres of their smallest root in [tmin, inf) and the LAST
-//     sphere of the caller's list among exact ties, so a candidate is taken if root < closest,
-//     or root == closest and it comes later in the caller's list (orig[]).
+//     discriminant (sphere data gathered from LDS) and the candidates in front of the ray are
+//     pushed to the lane's list.
+//   * pass 2 is the same exact root selection, with the order-free acceptance rule: the
+//     reference's scan returns the minimum over the spheres of their smallest root in
+//     [tmin, inf) and the LAST sphere of the caller's list among exact ties, so a candidate is
+//     taken if root < closest, or root == closest and it comes later in the caller's list.
 #ifndef RTW_CULL_GS
-#define RTW_CULL_GS 8   // spheres per cluster
+#define RTW_CULL_GS 16   // spheres per cluster (multiple of 8)
 #endif
+#define RTW_CULL_BG 4    // cluster boxes per SGPR set: 4 x 8 floats = 2 x s_load_dwordx16
 template <typename T> struct CullScene {
-    const typename Vec4<T>::type *bound;   // (Cx, Cy, Cz, R) per cluster, padded like geom (+ tail group)
+    const T *box;                          // 8 T per cluster: lo.xyz, pad, hi.xyz, pad; padded + tail group
     const typename Vec4<T>::type *exact;   // (cx, cy, cz, r*r), cluster-major then big class
     const unsigned short *orig;            // index in the caller's list
     const typename Vec4<T>::type *mat0;    // device order
     const typename Vec4<T>::type *mat1;
-    int n_groups_pad;                      // multiple of 2*ScanGroup<T>::N
+    int n_groups_pad;                      // multiple of 2*RTW_CULL_BG
     int n_big;                             // device indices n_groups_pad*GS .. +n_big-1
     T cs[3], rs;                           // bounding sphere of the small class
     T kappa;
 };
 template <typename T> __host__ __device__ inline int cull_exact_count(const CullScene<T> &c) { return c.n_groups_pad * RTW_CULL_GS + c.n_big; }
+
+__device__ __forceinline__ float t_min(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float t_max(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double t_min(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double t_max(double a, double b) { return __builtin_fmax(a, b); }
 
 template <typename T, int STRIDE, typename SRC, typename ORIG>
 __device__ __forceinline__ void resolve_candidates_anyorder(SRC src, ORIG orig, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
@@ -416,12 +425,10 @@ template <typename T, int STRIDE, typename SRC, typename ORIG, typename CLK = No
 __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, ORIG orig, V3<T> o, V3<T> d, T tmin, T tmax,
                                               T &t_hit, unsigned short *list, CLK &&clk = NoClock()) {
     using V4 = typename Vec4<T>::type;
-    constexpr int G = ScanGroup<T>::N;
+    constexpr int G = RTW_CULL_BG;
     constexpr int GS = RTW_CULL_GS;
     typedef const T __attribute__((address_space(4))) *cptr;
-    cptr gb = (cptr)(uintptr_t)w.bound;
     cptr gx = (cptr)(uintptr_t)w.exact;
-    auto ldg = [](cptr p, int k) -> V4 { return V4{p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]}; };
     T closest = tmax;
     int idx = -1, cnt = 0;
     auto push = [&](int i) {                       // lane-local: may run in divergent code
@@ -432,39 +439,54 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
         list[cnt * STRIDE] = (unsigned short)i;
         cnt += 1;
     };
+    // A root >= tmin > 0 needs half_b <= 0 or disc > half_b^2 (else -half_b + sqrt(disc) <= 0):
+    // spheres entirely behind the ray are not even listed.
+    auto member = [&](const V4 &sp, int i) {
+        T hb, disc;
+        sphere_disc<T>(sp.x, sp.y, sp.z, sp.w, o, d, hb, disc);
+        if (!(disc < T(0))) { if (!(hb > T(0)) || disc > hb * hb) push(i); }
+    };
 
     // big class: contract discriminant for every lane (wave-uniform sphere data)
     const int big0 = w.n_groups_pad * GS;
     for (int b = 0; b < w.n_big; ++b) {
         const int i = big0 + b;
-        T hb, disc;
-        sphere_disc<T>(gx[4 * i], gx[4 * i + 1], gx[4 * i + 2], gx[4 * i + 3], o, d, hb, disc);
-        if (!(disc < T(0))) { if (!(hb > T(0)) || disc > hb * hb) push(i); }
+        member(V4{gx[4 * i], gx[4 * i + 1], gx[4 * i + 2], gx[4 * i + 3]}, i);
     }
 
-    // per-ray inflation of the cluster radii
+    // per-ray constants of the slab test
     const V3<T> ocs = {o.x - w.cs[0], o.y - w.cs[1], o.z - w.cs[2]};
     const T margin = w.kappa * ((t_sqrt(dot(ocs, ocs)) + w.rs) + T(1));
+    auto safe_inv = [](T x) { const T e = T(1e-9); const T y = (x < e && x > -e) ? (x < T(0) ? -e : e) : x; return T(1) / y; };
+    const V3<T> inv = {safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
+    const V3<T> op = {o.x + margin, o.y + margin, o.z + margin};     // lo' - o = lo - (o + m)
+    const V3<T> om = {o.x - margin, o.y - margin, o.z - margin};     // hi' - o = hi - (o - m)
 
-    V4 A[G], B[G];
+    struct Box { T lx, ly, lz, l_, hx, hy, hz, h_; };
+    cptr gb = (cptr)(uintptr_t)w.box;
+    auto ldb = [](cptr p, int k) -> Box { return Box{p[8 * k], p[8 * k + 1], p[8 * k + 2], p[8 * k + 3], p[8 * k + 4], p[8 * k + 5], p[8 * k + 6], p[8 * k + 7]}; };
+    Box A[G], B[G];
 #pragma unroll
-    for (int k = 0; k < G; ++k) A[k] = ldg(gb, k);
+    for (int k = 0; k < G; ++k) A[k] = ldb(gb, k);
     cptr pw = gb;
-    auto test1 = [&](const V4 &sp, uint32_t &mask) {        // one cluster bound: 13 VALU ops
-        const T rm = sp.w + margin;
-        T hb, disc;
-        sphere_disc<T>(sp.x, sp.y, sp.z, rm * rm, o, d, hb, disc);
-        mask = __builtin_amdgcn_alignbit(mask, sign_word(disc), 31);
+    auto test1 = [&](const Box &bx, uint32_t &mask) {       // one cluster box: 23 VALU ops
+        const T x0 = (bx.lx - op.x) * inv.x, x1 = (bx.hx - om.x) * inv.x;
+        const T y0 = (bx.ly - op.y) * inv.y, y1 = (bx.hy - om.y) * inv.y;
+        const T z0 = (bx.lz - op.z) * inv.z, z1 = (bx.hz - om.z) * inv.z;
+        const T tn = t_max(t_max(t_min(x0, x1), t_min(y0, y1)), t_min(z0, z1));
+        const T tf = t_min(t_min(t_max(x0, x1), t_max(y0, y1)), t_max(z0, z1));
+        const T sgn = tf - t_max(tn, T(0));                  // >= 0 <=> the ray (t >= 0) meets the grown box
+        mask = __builtin_amdgcn_alignbit(mask, sign_word(sgn), 31);
     };
     for (int base = 0; base < w.n_groups_pad; base += RTW_SPHERE_WORD) {
         uint32_t mask = 0;
         const int left = w.n_groups_pad - base;
         const int npairs = left >= RTW_SPHERE_WORD ? RTW_SPHERE_WORD / (2 * G) : left / (2 * G);
-        for (int q = 0; q < npairs; ++q, pw += 2 * G * 4) {
+        for (int q = 0; q < npairs; ++q, pw += 2 * G * 8) {
             test1(A[0], mask);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < G; ++k) B[k] = ldg(pw, G + k);
+            for (int k = 0; k < G; ++k) B[k] = ldb(pw, G + k);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 1; k < G; ++k) test1(A[k], mask);
@@ -472,7 +494,7 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
             test1(B[0], mask);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < G; ++k) A[k] = ldg(pw, 2 * G + k);
+            for (int k = 0; k < G; ++k) A[k] = ldb(pw, 2 * G + k);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 1; k < G; ++k) test1(B[k], mask);
@@ -481,22 +503,19 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
         clk.lap(2);
         uint32_t m = ~mask;                       // bit 31 = cluster `base`
         if (left < RTW_SPHERE_WORD) m <<= (RTW_SPHERE_WORD - npairs * 2 * G);
-        // level 2: each lane expands the clusters its ray can touch
+        // level 2: each lane expands the clusters its ray can touch, 8 members at a time
         while (__any(m != 0u)) {
             if (m != 0u) {
                 const int b = __clz((int)m);
                 m &= ~(0x80000000u >> b);
                 const int first = (base + b) * GS;
-                V4 sp[GS];
+#pragma unroll 1
+                for (int h = 0; h < GS; h += 8) {
+                    V4 sp[8];
 #pragma unroll
-                for (int j = 0; j < GS; ++j) sp[j] = src[first + j];
+                    for (int j = 0; j < 8; ++j) sp[j] = src[first + h + j];
 #pragma unroll
-                for (int j = 0; j < GS; ++j) {
-                    T hb, disc;
-                    sphere_disc<T>(sp[j].x, sp[j].y, sp[j].z, sp[j].w, o, d, hb, disc);
-                    // rare branch.  A root >= tmin > 0 needs half_b <= 0 or disc > half_b^2 (else
-                    // -half_b + sqrt(disc) <= 0): spheres entirely behind the ray are not even listed.
-                    if (!(disc < T(0))) { if (!(hb > T(0)) || disc > hb * hb) push(first + j); }
+                    for (int j = 0; j < 8; ++j) member(sp[j], first + h + j);
                 }
             }
         }

@@ -133,7 +133,7 @@ template <typename T, typename SceneT>
 int build_cull(const SceneT *s, rtw_scene_dev *h) {
     using V4 = typename rtw::Vec4<T>::type;
     const int n = s->n;
-    constexpr int pair = 2 * rtw::ScanGroup<T>::N, GS = RTW_CULL_GS;
+    constexpr int pair = 2 * RTW_CULL_BG, GS = RTW_CULL_GS;
     // BIG class: |r| > 4 x lower-median |r| (the ground sphere, the unit spheres of scene_random_spheres)
     std::vector<int> small_ids, big_ids;
     if (n > 0) {
@@ -151,10 +151,11 @@ int build_cull(const SceneT *s, rtw_scene_dev *h) {
     const int n_big = (int)big_ids.size();
     const int n_exact = ng_pad * GS + n_big;
     if (n_exact >= 65536) return fail(-5, "too many spheres (%d) for the group-cull layout", n);
-    std::vector<V4> bound(ng_pad + RTW_SPHERE_TAIL), exact(std::max(n_exact, 1)), mat0(std::max(n_exact, 1)), mat1(std::max(n_exact, 1));
+    std::vector<T> box((size_t)(ng_pad + RTW_CULL_BG) * 8);            // + one prefetch group
+    std::vector<V4> exact(std::max(n_exact, 1)), mat0(std::max(n_exact, 1)), mat1(std::max(n_exact, 1));
     std::vector<unsigned short> orig(std::max(n_exact, 1), 0);
     // dead cluster: far away and empty; dead sphere: r^2 = -1e30 (never a candidate)
-    for (auto &b : bound) b = V4{(T)1e15, (T)1e15, (T)1e15, (T)0};
+    for (auto &b : box) b = (T)1e15;                                    // dead cluster: a point far away
     for (int k = 0; k < n_exact; ++k) { exact[k] = V4{(T)0, (T)0, (T)0, (T)-1e30}; mat0[k] = V4{(T)1, (T)0, (T)0, (T)0}; mat1[k] = V4{(T)0, (T)0, (T)0, (T)0}; }
     auto put = [&](int k, int i) {
         exact[k] = V4{s->cx[i], s->cy[i], s->cz[i], s->r[i] * s->r[i]};
@@ -168,33 +169,34 @@ int build_cull(const SceneT *s, rtw_scene_dev *h) {
     if (nsm) { cs[0] /= nsm; cs[1] /= nsm; cs[2] /= nsm; }
     for (int gi = 0; gi < ng; ++gi) {
         const auto &g = groups[gi];
-        double c[3] = {0, 0, 0};
-        for (int i : g) { c[0] += s->cx[i]; c[1] += s->cy[i]; c[2] += s->cz[i]; }
-        for (int a = 0; a < 3; ++a) c[a] /= (double)g.size();
-        const T cT[3] = {(T)c[0], (T)c[1], (T)c[2]};                     // the ROUNDED centre is the bound's centre
-        double R = 0;
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int j = 0; j < (int)g.size(); ++j) {
             const int i = g[j];
-            const double dx = (double)s->cx[i] - cT[0], dy = (double)s->cy[i] - cT[1], dz = (double)s->cz[i] - cT[2];
-            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)s->r[i]));
+            const double c[3] = {(double)s->cx[i], (double)s->cy[i], (double)s->cz[i]}, ar = std::fabs((double)s->r[i]);
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a] - ar); hi[a] = std::max(hi[a], c[a] + ar); }
             put(gi * GS + j, i);
-            const double ex = (double)s->cx[i] - cs[0], ey = (double)s->cy[i] - cs[1], ez = (double)s->cz[i] - cs[2];
-            rs = std::max(rs, std::sqrt(ex * ex + ey * ey + ez * ez) + std::fabs((double)s->r[i]));
+            const double ex = c[0] - cs[0], ey = c[1] - cs[1], ez = c[2] - cs[2];
+            rs = std::max(rs, std::sqrt(ex * ex + ey * ey + ez * ez) + ar);
         }
-        bound[gi] = V4{cT[0], cT[1], cT[2], (T)(R * (1.0 + 1e-5) + 1e-30)};
-        if ((double)bound[gi].w < R) bound[gi].w = std::nextafter(bound[gi].w, (T)INFINITY);
+        for (int a = 0; a < 3; ++a) {                                    // round outwards
+            T l = (T)lo[a], u2 = (T)hi[a];
+            if ((double)l > lo[a]) l = std::nextafter(l, (T)-INFINITY);
+            if ((double)u2 < hi[a]) u2 = std::nextafter(u2, (T)INFINITY);
+            box[(size_t)gi * 8 + a] = l; box[(size_t)gi * 8 + 4 + a] = u2;
+        }
+        box[(size_t)gi * 8 + 3] = box[(size_t)gi * 8 + 7] = (T)0;
     }
     for (int k = 0; k < n_big; ++k) put(ng_pad * GS + k, big_ids[k]);
     h->c_groups_pad = ng_pad; h->c_big = n_big;
     h->c_cs[0] = (double)(T)cs[0]; h->c_cs[1] = (double)(T)cs[1]; h->c_cs[2] = (double)(T)cs[2];
     h->c_rs = rs * (1.0 + 1e-5) + 1e-3 * (std::fabs(cs[0]) + std::fabs(cs[1]) + std::fabs(cs[2])) * (sizeof(T) == 4 ? 1e-4 : 1e-12);
-    const size_t bb = sizeof(V4) * bound.size(), eb = sizeof(V4) * exact.size(), ob = sizeof(unsigned short) * orig.size();
+    const size_t bb = sizeof(T) * box.size(), eb = sizeof(V4) * exact.size(), ob = sizeof(unsigned short) * orig.size();
     HIP_TRY(hipMalloc(&h->c_bound, bb));
     HIP_TRY(hipMalloc(&h->c_exact, eb));
     HIP_TRY(hipMalloc(&h->c_mat0, eb));
     HIP_TRY(hipMalloc(&h->c_mat1, eb));
     HIP_TRY(hipMalloc((void **)&h->c_orig, ob));
-    HIP_TRY(hipMemcpy(h->c_bound, bound.data(), bb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->c_bound, box.data(), bb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->c_exact, exact.data(), eb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->c_mat0, mat0.data(), eb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->c_mat1, mat1.data(), eb, hipMemcpyHostToDevice));
@@ -206,7 +208,7 @@ template <typename T>
 rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
     using V4 = typename rtw::Vec4<T>::type;
     rtw::CullScene<T> C;
-    C.bound = (const V4 *)h->c_bound; C.exact = (const V4 *)h->c_exact; C.orig = h->c_orig;
+    C.box = (const T *)h->c_bound; C.exact = (const V4 *)h->c_exact; C.orig = h->c_orig;
     C.mat0 = (const V4 *)h->c_mat0; C.mat1 = (const V4 *)h->c_mat1;
     C.n_groups_pad = h->c_groups_pad; C.n_big = h->c_big;
     C.cs[0] = (T)h->c_cs[0]; C.cs[1] = (T)h->c_cs[1]; C.cs[2] = (T)h->c_cs[2]; C.rs = (T)h->c_rs;

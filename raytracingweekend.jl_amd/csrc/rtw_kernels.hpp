@@ -64,12 +64,19 @@ __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi
 #endif
 template <typename T> struct TraceWaves { static constexpr int value = RTW_TRACE_WAVES_F32; };
 template <> struct TraceWaves<double> { static constexpr int value = 4; };
+// the group-cull variant keeps the slab-test constants live across the scan: fewer waves, no spills
+#ifndef RTW_TRACE_WAVES_CULL_F32
+#define RTW_TRACE_WAVES_CULL_F32 5
+#endif
+template <typename T, bool CULL> struct TraceWavesOf { static constexpr int value = TraceWaves<T>::value; };
+template <> struct TraceWavesOf<float, true> { static constexpr int value = RTW_TRACE_WAVES_CULL_F32; };
+template <> struct TraceWavesOf<double, true> { static constexpr int value = 3; };
 #ifndef RTW_ITEM_BATCH
 #define RTW_ITEM_BATCH 64u   // work items a wave takes from the global queue per atomic
 #endif
 
 template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL>
-__global__ __launch_bounds__(256, TraceWaves<T>::value) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,
+__global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,
                                                    CullScene<T> cull, const T *__restrict__ puv,
                                                    double *__restrict__ partial, DevCounters *ctr) {
     using V4 = typename Vec4<T>::type;
