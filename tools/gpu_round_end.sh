@@ -16,3 +16,6 @@ for g in sorted(glob.glob("$R/gpurun_out/round/pmc*/*counter_collection.csv")):
     for row in csv.DictReader(open(g)):
         print(row["Kernel_Name"][:40], row["Counter_Name"], row["Counter_Value"])
 PY
+# the opt-in accelerated mode, same procedure
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/round/trace_cull -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --group-cull > $R/gpurun_out/round/trace_cull.log 2>&1
+echo "== group-cull kernel stats"; cat $R/gpurun_out/round/trace_cull/*kernel_stats.csv
