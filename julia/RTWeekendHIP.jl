@@ -57,13 +57,14 @@ matparam(m::Dielectric{T}) where T = m.ir
 last_error() = unsafe_string(ccall((:rtw_last_error, LIB), Cstring, ()))
 
 """
-    render(scene, cam, image_width=400, n_samples=1; depth=16, seed=1, n_chunks=0, device=-1)
+    render(scene, cam, image_width=400, n_samples=1; depth=16, seed=1, n_chunks=0, device=-1, group_cull=false)
 
 Drop-in for `RayTracingWeekend.render` (src/render.jl:8-44) on one MI355X.  Keyword extras only.
 `depth=16` is the reference's hard-wired `ray_color` default (src/ray_color.jl:14).
+`group_cull=true` selects the opt-in accelerated scan (RTW_FLAG_GROUP_CULL): same image bit for bit.
 """
 function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=1;
-                depth=16, seed=1, n_chunks=0, device=-1) where T <: Union{Float32,Float64}
+                depth=16, seed=1, n_chunks=0, device=-1, group_cull=false) where T <: Union{Float32,Float64}
     image_height = image_width ÷ (16//9)                       # src/render.jl:11-12
     n = length(scene)
     cx = Vector{T}(undef, n); cy = similar(cx); cz = similar(cx); r = similar(cx)
@@ -79,7 +80,7 @@ function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=
     end
     img = Matrix{RGB{T}}(undef, image_height, image_width)      # column-major H x W, 3 x T per pixel
     ccam = Ref(CCamera(cam))
-    params = Ref(CParams(image_width, image_height, n_samples, depth, seed, n_chunks, 0, 1, device, 1, 0))
+    params = Ref(CParams(image_width, image_height, n_samples, depth, seed, n_chunks, 0, 1, device, 1, group_cull ? 1 : 0))
     rc = GC.@preserve cx cy cz r kind ar ag ab param img begin
         cscene = Ref(CScene{T}(n, pointer(cx), pointer(cy), pointer(cz), pointer(r), pointer(kind),
                                pointer(ar), pointer(ag), pointer(ab), pointer(param)))
