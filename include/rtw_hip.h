@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RTW_ABI_VERSION 1
+#define RTW_ABI_VERSION 2
 
 /* Material kinds: Lambertian / Metal / Dielectric (src/material.jl:3-5, 25-29, 37-39). */
 enum { RTW_LAMBERTIAN = 0, RTW_METAL = 1, RTW_DIELECTRIC = 2 };
@@ -61,6 +61,11 @@ typedef struct {
  * spheres are clustered at upload and clusters whose inflated bounding sphere a ray provably
  * misses are skipped.  Bit-identical images; default (0) is the reference's plain linear scan. */
 #define RTW_FLAG_GROUP_CULL 1
+/* RTW_FLAG_COMPACT_TILES (device-resident entry points): write only this shard's 8x8 tiles, tile-major
+ * and compact -- local tile k (global tile k*shard_count + shard_index, tiles numbered column-major like
+ * the image) at [k*64 + (i mod 8) + 8*(j mod 8)]*3 -- instead of the zero-padded full frame: the buffer is
+ * ceil((n_tiles - shard_index) / shard_count) * 192 elements and a gather moves 1/shard_count of the frame. */
+#define RTW_FLAG_COMPACT_TILES 2
 
 /* Positional arguments of render() plus the keyword extras of the shim. */
 typedef struct {
@@ -70,21 +75,30 @@ typedef struct {
     int32_t max_depth;    /* ray_color depth; reference default 16 (src/ray_color.jl:14)      */
     uint64_t seed;        /* render seed; the stream of (pixel, chunk) derives from it        */
     int32_t n_chunks;     /* sample chunks per pixel, each with its own RNG stream;
-                             0 = default rule min(spp, 128).  Part of the image definition.    */
+                             0 = default rule min(spp, 128).  Part of the image definition
+                             (the chunk sums themselves are added exactly, in any order).      */
     int32_t shard_index;  /* this call renders the 8x8 pixel tiles t with                      */
     int32_t shard_count;  /*   t mod shard_count == shard_index; other pixels are written 0    */
     int32_t device;       /* HIP device ordinal; -1 = current device                          */
     int32_t gamma;        /* 1 = sqrt per channel (rgb_gamma2, src/vec.jl:22); 0 = linear mean */
     int32_t flags;        /* 0, or RTW_FLAG_* (opt-in modes; the image is identical in every mode)    */
+    int32_t n_devices;    /* rtw_render_f32/_f64 only (Julia keyword `devices`): 0 or 1 = the one device
+                             named by `device`; N > 1 = the N ordinals in device_ids; -1 = every visible
+                             device.  The 8x8 tiles are dealt round-robin to the devices (one host thread,
+                             stream and PCIe link each); the image is identical for every device list.   */
+    int32_t reserved;     /* 0 */
+    const int32_t *device_ids; /* n_devices > 1: HIP ordinals; an ordinal may repeat (its shards then run
+                             concurrently on that device)                                               */
 } rtw_params;
 
-/* Counters of the most recent render on the calling thread's device context. */
+/* Counters of the most recent render issued from the calling thread (summed over its devices;
+ * times are the maximum over the devices). */
 typedef struct {
     uint64_t samples;       /* pixel samples taken by this shard                              */
     uint64_t segments;      /* ray segments == closest-hit scans (src/hit.jl:38-50)           */
     uint64_t sphere_tests;  /* segments * n spheres (src/hit.jl:12-35 evaluations)            */
-    double kernel_ms;       /* HIP-event time of the trace kernel (the dominant kernel)       */
-    double total_ms;        /* HIP-event time of the whole device-side render (all kernels)   */
+    double kernel_ms;       /* HIP-event time of the trace kernel (the only kernel of a render) */
+    double total_ms;        /* same (kept from ABI 1, where a second kernel stored the image)  */
     int32_t n_chunks;       /* chunks per pixel actually used                                 */
     int32_t grid_blocks;    /* trace kernel launch geometry                                   */
     int32_t block_threads;
@@ -108,7 +122,9 @@ int rtw_render_f64(const rtw_scene_f64 *scene, const rtw_camera_f64 *cam, const 
  * multi-process sharding over RCCL).  `scene` is a handle from rtw_scene_upload_*; `d_out` is a
  * DEVICE pointer to height*width*3 elements; `hip_stream` is a hipStream_t passed as void*
  * (NULL = the null stream).  Asynchronous with respect to the host: work is enqueued on the
- * stream; rtw_stats() synchronises with it. */
+ * stream and nothing is waited for; rtw_stats() synchronises with it.  Re-entrant: any number of
+ * renders may be in flight on any mix of streams, host threads and devices (each call owns its
+ * counters; there is no shared device workspace). */
 typedef struct rtw_scene_dev *rtw_scene_handle;
 int rtw_scene_upload_f32(const rtw_scene_f32 *scene, int device, rtw_scene_handle *out);
 int rtw_scene_upload_f64(const rtw_scene_f64 *scene, int device, rtw_scene_handle *out);
@@ -125,13 +141,16 @@ int rtw_stats(rtw_stats_t *out);
  * device implementation of one reference function on `count` inputs, one lane per input.
  * All pointers are HOST pointers; layouts are documented in tests/test_gpu_units.py.
  *   op: 0 hit_sphere  1 reflect  2 refract  3 reflectance  4 scatter  5 get_ray  6 skycolor
- *       7 rng_f (uniforms from a stream state)  8 hit_world                                  */
+ *       7 rng_f (uniforms from a stream state)  8 hit_world  9 ray_color
+ *       10 hit_world, scene staged in LDS  11 hit_world_cull (RTW_FLAG_GROUP_CULL)
+ *       12 exact 64.64 fixed-point accumulation of 8 doubles                                   */
 int rtw_unit_f32(int op, int count, const void *in, void *out, const rtw_scene_f32 *scene,
                  const rtw_camera_f32 *cam);
 int rtw_unit_f64(int op, int count, const void *in, void *out, const rtw_scene_f64 *scene,
                  const rtw_camera_f64 *cam);
 
-/* Frees cached per-device workspaces.  Optional. */
+/* Frees the cached per-device render records (counters, events).  Optional.  Afterwards
+ * rtw_stats() reports "no render" on every thread until that thread renders again. */
 int rtw_shutdown(void);
 
 #ifdef __cplusplus

@@ -105,6 +105,68 @@ static inline double tand_f64(double x) { return (double)tand_ld((long double)x)
 
 int rtwo_max_threads(void) { return omp_get_max_threads(); }
 
+/* ------------------------------------------------------------------------------------------
+ * PIXEL_STREAM pixel accumulation: the chunk sums of one pixel are
+ * added EXACTLY -- each binary64 chunk sum is converted to a signed 64.64 fixed-point number
+ * (every double of magnitude in [2^-11, 2^31) is represented exactly; smaller magnitudes are
+ * truncated towards zero at 2^-64) and the fixed-point numbers are added as 128-bit integers.
+ * The pixel sum is that integer rounded ONCE to binary64 (round to nearest, ties to even).
+ * Integer addition is associative, so the result does not depend on the order in which the
+ * chunks finish -- which is what lets the device add them with LDS atomics in any order.
+ * The reference itself adds the samples sequentially in Float64 (src/render.jl:29-39); this
+ * is at least as accurate (one rounding per pixel instead of one per sample after the chunk).
+ * A chunk sum that is NaN, infinite or >= 2^31 in magnitude poisons the pixel (NaN output).
+ * ------------------------------------------------------------------------------------------ */
+typedef unsigned __int128 u128;
+typedef struct { u128 v[3]; uint32_t poison; } fxacc;
+
+static inline int fx_from_double(double x, u128 *out) {
+    double a = fabs(x);
+    if (!(a < 2147483648.0)) return 0;                       /* NaN, Inf, >= 2^31 */
+    uint32_t ip = (uint32_t)a;                               /* trunc(|x|) < 2^31 */
+    double fr = a - (double)ip;                              /* exact, in [0, 1) */
+    double y = fr * 4294967296.0;                            /* exact scaling by 2^32 */
+    uint32_t p1 = (uint32_t)y;                               /* bits 2^-1 .. 2^-32 */
+    double r1 = y - (double)p1;                              /* exact, in [0, 1) */
+    uint32_t p0 = (uint32_t)(r1 * 4294967296.0);             /* bits 2^-33 .. 2^-64, truncated */
+    u128 m = ((u128)ip << 64) | ((u128)p1 << 32) | (u128)p0;
+    *out = x < 0.0 ? (u128)0 - m : m;
+    return 1;
+}
+static inline void fx_add(fxacc *acc, int ch, double x) {
+    u128 q;
+    if (fx_from_double(x, &q)) acc->v[ch] += q; else acc->poison++;
+}
+static inline double fx_to_double(u128 a) {
+    int neg = (int)(a >> 127);
+    if (neg) a = (u128)0 - a;
+    if (a == 0) return 0.0;
+    uint64_t hi = (uint64_t)(a >> 64), lo = (uint64_t)a;
+    int p = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo);   /* index of the top set bit */
+    double m;
+    int sh = 0;
+    if (p <= 52) {
+        m = (double)lo;                                                  /* < 2^53: exact */
+    } else {
+        sh = p - 52;
+        uint64_t mant = (uint64_t)(a >> sh);                             /* top 53 bits */
+        u128 rem = a & ((((u128)1) << sh) - 1), half = ((u128)1) << (sh - 1);
+        if (rem > half || (rem == half && (mant & 1))) mant++;           /* ties to even */
+        m = (double)mant;                                                /* <= 2^53: exact */
+    }
+    double v = ldexp(m, sh - 64);
+    return neg ? -v : v;
+}
+
+/* unit-level exports of the fixed-point accumulation (tests/test_oracle_kats.py) */
+double rtwo_fx_sum(const double *x, int n, int *poisoned) {
+    fxacc a; memset(&a, 0, sizeof a);
+    for (int i = 0; i < n; ++i) fx_add(&a, 0, x[i]);
+    if (poisoned) *poisoned = (int)a.poison;
+    return a.poison ? NAN : fx_to_double(a.v[0]);
+}
+
+
 /* ---- Float32 (mixed precision) ------------------------------------------------ */
 #define T float
 #define SUF f32

@@ -278,5 +278,15 @@ def rng_float(st, T=np.float64):
     return np.dtype(T).type(fn(_p(st)))
 
 
+def fx_sum(values):
+    """exact 64.64 fixed-point sum of binary64 values rounded once -> (sum, n_poisoned)"""
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    fn = lib().rtwo_fx_sum
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    bad = C.c_int(0)
+    return float(fn(_p(a), int(a.size), C.byref(bad))), int(bad.value)
+
+
 def max_threads():
     return int(lib().rtwo_max_threads())

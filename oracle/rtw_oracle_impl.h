@@ -319,7 +319,8 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
         }
     } else {
         /* PIXEL_STREAM: one independent Xoroshiro128+ stream per (pixel, sample chunk); the
-         * chunk sums are added in chunk order.  This is what a parallel device can reproduce. */
+         * chunk sums (sequential binary64 sums of the chunk's samples) are added exactly and
+         * rounded once.  This is what a parallel device can reproduce in any completion order. */
         int nch = P->n_chunks > 0 ? P->n_chunks : 1;
         int cs = (P->spp + nch - 1) / nch;
         int nch_eff = (P->spp + cs - 1) / cs;
@@ -329,7 +330,7 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
             int j = (int)(pix / H) + 1, i = (int)(pix % H) + 1;
             T u = (T)((double)j / (double)W);
             T v = (T)((double)(H - i) / (double)H);
-            c3 acc = {0.0, 0.0, 0.0};
+            fxacc fx; memset(&fx, 0, sizeof fx);
             octx c; c.draws = 0; c.segments = 0;
             g_cand_disc = 0; g_cand_fwd = 0;
             for (int ch = 0; ch < nch_eff; ++ch) {
@@ -340,8 +341,11 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
                     c3 col = FN(sample_)(&c, w, cam, P, u, v, s);
                     cs_sum.r += col.r; cs_sum.g += col.g; cs_sum.b += col.b;
                 }
-                acc.r += cs_sum.r; acc.g += cs_sum.g; acc.b += cs_sum.b;
+                /* exact (order-independent) addition of the chunk sums: rtw_oracle.c fx_add */
+                fx_add(&fx, 0, cs_sum.r); fx_add(&fx, 1, cs_sum.g); fx_add(&fx, 2, cs_sum.b);
             }
+            c3 acc = {fx_to_double(fx.v[0]), fx_to_double(fx.v[1]), fx_to_double(fx.v[2])};
+            if (fx.poison) acc.r = acc.g = acc.b = NAN;
             FN(store_)(P, out, i, j, acc);
             tot_draws += c.draws; tot_segments += c.segments; tot_cd += g_cand_disc; tot_cf += g_cand_fwd;
         }

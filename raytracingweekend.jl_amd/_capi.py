@@ -36,7 +36,8 @@ CameraF32, CameraF64 = _camera_struct(C.c_float), _camera_struct(C.c_double)
 class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("seed", C.c_uint64), ("n_chunks", C.c_int32), ("shard_index", C.c_int32),
-                ("shard_count", C.c_int32), ("device", C.c_int32), ("gamma", C.c_int32), ("flags", C.c_int32)]
+                ("shard_count", C.c_int32), ("device", C.c_int32), ("gamma", C.c_int32), ("flags", C.c_int32),
+                ("n_devices", C.c_int32), ("reserved", C.c_int32), ("device_ids", C.POINTER(C.c_int32))]
 
 
 class Stats(C.Structure):
@@ -116,10 +117,31 @@ def make_camera(cam, T):
     return Cm
 
 
-FLAG_GROUP_CULL = 1   # include/rtw_hip.h RTW_FLAG_GROUP_CULL
+FLAG_GROUP_CULL = 1      # include/rtw_hip.h RTW_FLAG_GROUP_CULL
+FLAG_COMPACT_TILES = 2   # include/rtw_hip.h RTW_FLAG_COMPACT_TILES
+ABI_VERSION = 2
 
 
 def make_params(width, height, spp, max_depth=16, seed=1, n_chunks=0, shard_index=0, shard_count=1,
-                device=-1, gamma=1, flags=0):
-    return Params(int(width), int(height), int(spp), int(max_depth), int(seed), int(n_chunks),
-                  int(shard_index), int(shard_count), int(device), int(gamma), int(flags))
+                device=-1, gamma=1, flags=0, devices=None):
+    """``devices``: None / int ordinal -> one device; "all" -> every visible device (n_devices = -1);
+    a sequence of ordinals -> that device list (host-buffer entry points only)."""
+    P = Params(int(width), int(height), int(spp), int(max_depth), int(seed), int(n_chunks),
+               int(shard_index), int(shard_count), int(device), int(gamma), int(flags), 0, 0, None)
+    if devices is None:
+        return P
+    if isinstance(devices, str):
+        if devices != "all":
+            raise ValueError("devices must be None, 'all', an ordinal or a sequence of ordinals")
+        P.n_devices = -1
+    elif isinstance(devices, (int, np.integer)):
+        P.device = int(devices)
+    else:
+        ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        P._keep_ids = ids                     # keep the array alive as long as the struct
+        if len(devices) == 1:
+            P.device = int(devices[0])
+        else:
+            P.n_devices = len(devices)
+            P.device_ids = C.cast(ids, C.POINTER(C.c_int32))
+    return P

@@ -79,24 +79,34 @@ template <typename T> __device__ __forceinline__ T random_between(Rng &r, T mn, 
     T u; trand(r, u);
     return u * (mx - mn) + mn;
 }
+// One trial of the rejection samplers: src/rand.jl:15-22 (unit ball: x, y, z) and :31-38 (unit
+// disk: x, y).  Returns the squared length p.p; the trial is accepted iff it is <= 1 (boundary
+// inclusive).  The disk form leaves z = +0, and (x*x + y*y) + 0*0 has the bits of x*x + y*y, so
+// one expression serves both; lanes of a wave that need a ball sample and lanes that need a disk
+// sample run the SAME loop (rtw_kernels.hpp phase R), each consuming its own stream exactly as
+// the reference's two separate loops would.
+template <typename T> __device__ __forceinline__ T reject_trial(Rng &r, bool ball, V3<T> &p) {
+    p.x = random_between(r, T(-1), T(1));
+    p.y = random_between(r, T(-1), T(1));
+    p.z = T(0);
+    if (ball) p.z = random_between(r, T(-1), T(1));
+    return (p.x * p.x + p.y * p.y) + p.z * p.z;
+}
+// normalize(p) when p.p is already known: StaticArrays' inv(norm(p)) * p with norm = sqrt(p.p)
+template <typename T> __device__ __forceinline__ V3<T> normalize_len2(V3<T> p, T len2) {
+    return vscale(T(1) / t_sqrt(len2), p);
+}
 // src/rand.jl:15-22,29: rejection in the unit ball (x,y,z order, boundary inclusive), normalised
 template <typename T> __device__ __forceinline__ V3<T> random_vec3_on_sphere(Rng &r) {
-    V3<T> p;
-    for (;;) {
-        p.x = random_between(r, T(-1), T(1));
-        p.y = random_between(r, T(-1), T(1));
-        p.z = random_between(r, T(-1), T(1));
-        if (dot(p, p) <= T(1)) break;
-    }
-    return normalize(p);
+    V3<T> p; T len2;
+    do { len2 = reject_trial<T>(r, true, p); } while (!(len2 <= T(1)));
+    return normalize_len2(p, len2);
 }
 // src/rand.jl:31-38
 template <typename T> __device__ __forceinline__ void random_vec2_in_disk(Rng &r, T &x, T &y) {
-    for (;;) {
-        x = random_between(r, T(-1), T(1));
-        y = random_between(r, T(-1), T(1));
-        if (x * x + y * y <= T(1)) break;
-    }
+    V3<T> p; T len2;
+    do { len2 = reject_trial<T>(r, false, p); } while (!(len2 <= T(1)));
+    x = p.x; y = p.y;
 }
 
 // ---- intersection (src/hit.jl) ---------------------------------------------------------------
@@ -140,13 +150,17 @@ template <typename T> __device__ __forceinline__ V3<T> reflect(V3<T> v, V3<T> n)
     T k = dot(vscale(T(2), v), n);
     return vsub(v, vscale(k, n));
 }
-template <typename T> __device__ __forceinline__ V3<T> refract(V3<T> dir, V3<T> n, T ratio) {  // :12-17
+// refract (:12-17) is normalize(perp + par); refract_raw is the vector before the normalize
+template <typename T> __device__ __forceinline__ V3<T> refract_raw(V3<T> dir, V3<T> n, T ratio) {
     T cos_t = -dot(dir, n);
     if (!(T(1) > cos_t)) cos_t = T(1);
     V3<T> perp = vscale(ratio, vadd(dir, vscale(cos_t, n)));
     T one_m = T(1) - dot(perp, perp);
     T par_s = -t_sqrt(one_m < T(0) ? -one_m : one_m);
-    return normalize(vadd(perp, vscale(par_s, n)));
+    return vadd(perp, vscale(par_s, n));
+}
+template <typename T> __device__ __forceinline__ V3<T> refract(V3<T> dir, V3<T> n, T ratio) {  // :12-17
+    return normalize(refract_raw(dir, n, ratio));
 }
 template <typename T> __device__ __forceinline__ T reflectance(T cos_t, T ratio) {   // :19-25
     T r0 = (T(1) - ratio) / (T(1) + ratio);
@@ -158,11 +172,17 @@ template <typename T> __device__ __forceinline__ T reflectance(T cos_t, T ratio)
 }
 
 // ---- materials (src/material.jl:13-53) -------------------------------------------------------
+// scatter is split at the random unit vector so that the trace kernel can run ONE rejection loop
+// and ONE final normalize for all lanes of a wave whatever they are doing (new camera ray,
+// Lambertian, Metal, refraction).  scatter() below composes the parts for one lane (T0 tests).
+enum { PATH_READY = 0,   // `vec` is the final direction as the reference leaves it
+       PATH_NORM = 1,    // final direction = normalize(vec)
+       PATH_BALL = 2 };  // needs a unit-ball sample: scatter_finish(kind, vec, scale, p, p.p)
 template <typename T>
-__device__ __forceinline__ void scatter(Rng &rng, int kind, V3<T> albedo, T param, V3<T> d_in,
-                                        const HitRec<T> &rec, V3<T> &out_d, V3<T> &att) {
+__device__ __forceinline__ int scatter_begin(Rng &rng, int kind, T param, V3<T> d_in, const HitRec<T> &rec,
+                                             V3<T> &vec, T &scale) {
+    scale = T(1);
     if (kind == DIELECTRIC) {                                     // :41-53
-        att = {T(1), T(1), T(1)};
         T ratio = rec.front ? (T(1) / param) : param;
         T cos_t = -dot(d_in, rec.n);
         if (!(T(1) > cos_t)) cos_t = T(1);
@@ -172,19 +192,38 @@ __device__ __forceinline__ void scatter(Rng &rng, int kind, V3<T> albedo, T para
             T u; trand(rng, u);
             refl = reflectance(cos_t, ratio) > u;
         }
-        out_d = refl ? reflect(d_in, rec.n) : refract(d_in, rec.n, ratio);
-    } else {
-        // Lambertian (:13-23) and Metal (:31-34) both start from one random unit vector
-        V3<T> uvec = random_vec3_on_sphere<T>(rng);
-        att = albedo;
-        if (kind == LAMBERTIAN) {
-            V3<T> dir = vadd(rec.n, uvec);
-            out_d = near_zero(dir) ? rec.n : normalize(dir);
-        } else {
-            V3<T> refl = reflect(d_in, rec.n);
-            out_d = normalize(vadd(refl, vscale(param, uvec)));
-        }
+        if (refl) { vec = reflect(d_in, rec.n); return PATH_READY; }   // :48, not re-normalised
+        vec = refract_raw(d_in, rec.n, ratio);                          // :50
+        return PATH_NORM;
     }
+    // Lambertian (:13-23): n + u;  Metal (:31-34): reflect(d, n) + fuzz * u
+    if (kind == LAMBERTIAN) { vec = rec.n; } else { vec = reflect(d_in, rec.n); scale = param; }
+    return PATH_BALL;
+}
+// p: the accepted unit-ball sample, len2 = p.p.  scale == 1 for Lambertian (1 * u == u exactly).
+template <typename T>
+__device__ __forceinline__ int scatter_finish(int kind, V3<T> base, T scale, V3<T> p, T len2, V3<T> &vec) {
+    V3<T> uvec = normalize_len2(p, len2);
+    V3<T> dir = vadd(base, vscale(scale, uvec));
+    if (kind == LAMBERTIAN && near_zero(dir)) { vec = base; return PATH_READY; }   // :15-16
+    vec = dir;
+    return PATH_NORM;
+}
+template <typename T> __device__ __forceinline__ V3<T> attenuation_of(int kind, V3<T> albedo) {
+    return kind == DIELECTRIC ? V3<T>{T(1), T(1), T(1)} : albedo;
+}
+template <typename T>
+__device__ __forceinline__ void scatter(Rng &rng, int kind, V3<T> albedo, T param, V3<T> d_in,
+                                        const HitRec<T> &rec, V3<T> &out_d, V3<T> &att) {
+    att = attenuation_of(kind, albedo);
+    V3<T> vec; T scale;
+    int path = scatter_begin<T>(rng, kind, param, d_in, rec, vec, scale);
+    if (path == PATH_BALL) {
+        V3<T> p; T len2;
+        do { len2 = reject_trial<T>(rng, true, p); } while (!(len2 <= T(1)));
+        path = scatter_finish<T>(kind, vec, scale, p, len2, vec);
+    }
+    out_d = path == PATH_NORM ? normalize(vec) : vec;
 }
 
 // ---- sky (src/ray_color.jl:1-6): Float64 constants ------------------------------------------
@@ -200,10 +239,9 @@ template <typename T> struct Camera {
     T origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3];
     T lens_radius;
 };
+// get_ray after the lens sample (dx, dy): origin and the un-normalised direction (:45-47)
 template <typename T>
-__device__ __forceinline__ void get_ray(Rng &rng, const Camera<T> &cam, T s, T t, V3<T> &ro, V3<T> &rd) {
-    T dx, dy;
-    random_vec2_in_disk(rng, dx, dy);
+__device__ __forceinline__ void camera_ray_raw(const Camera<T> &cam, T s, T t, T dx, T dy, V3<T> &ro, V3<T> &raw) {
     T rx = cam.lens_radius * dx, ry = cam.lens_radius * dy;
     V3<T> cu = {cam.u[0], cam.u[1], cam.u[2]}, cv = {cam.v[0], cam.v[1], cam.v[2]};
     V3<T> org = {cam.origin[0], cam.origin[1], cam.origin[2]};
@@ -215,8 +253,66 @@ __device__ __forceinline__ void get_ray(Rng &rng, const Camera<T> &cam, T s, T t
     V3<T> dir = vadd(llc, vscale(s, hor));
     dir = vadd(dir, vscale(t, ver));
     dir = vsub(dir, org);
-    dir = vsub(dir, offset);
-    rd = normalize(dir);
+    raw = vsub(dir, offset);
+}
+template <typename T>
+__device__ __forceinline__ void get_ray(Rng &rng, const Camera<T> &cam, T s, T t, V3<T> &ro, V3<T> &rd) {
+    T dx, dy;
+    random_vec2_in_disk(rng, dx, dy);
+    V3<T> raw;
+    camera_ray_raw(cam, s, t, dx, dy, ro, raw);
+    rd = normalize(raw);
+}
+
+// ---- exact pixel accumulation (oracle/rtw_oracle.c fx_add) --------------
+// A chunk sum (binary64) as signed 64.64 fixed point in two's complement (hi:lo).  Exact for
+// magnitudes in [2^-11, 2^31); smaller ones are truncated towards zero at 2^-64.  false = the
+// value is NaN, infinite or >= 2^31: it poisons the pixel.
+__device__ __forceinline__ bool fx_from_double(double x, unsigned long long &lo, unsigned long long &hi) {
+    const double a = __builtin_fabs(x);
+    if (!(a < 2147483648.0)) return false;
+    const unsigned ip = (unsigned)a;                       // trunc(|x|)
+    const double fr = a - (double)ip;                      // exact, in [0, 1)
+    const double y = fr * 4294967296.0;                    // exact
+    const unsigned p1 = (unsigned)y;
+    const double r1 = y - (double)p1;                      // exact, in [0, 1)
+    const unsigned p0 = (unsigned)(r1 * 4294967296.0);     // truncated at 2^-64
+    unsigned long long l = ((unsigned long long)p1 << 32) | (unsigned long long)p0, h = ip;
+    if (x < 0.0) { l = 0ull - l; h = ~h + (l == 0ull ? 1ull : 0ull); }
+    lo = l; hi = h;
+    return true;
+}
+// the 128-bit sum rounded once to binary64, round to nearest, ties to even
+__device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned long long hi) {
+    const bool neg = (long long)hi < 0;
+    if (neg) { lo = 0ull - lo; hi = ~hi + (lo == 0ull ? 1ull : 0ull); }
+    if ((lo | hi) == 0ull) return 0.0;
+    const int p = hi ? 127 - __clzll((long long)hi) : 63 - __clzll((long long)lo);   // top set bit
+    double m;
+    int sh = 0;
+    if (p <= 52) {
+        m = (double)lo;
+    } else {
+        sh = p - 52;                                       // 1 .. 75
+        unsigned long long mant, rem_hi, rem_lo, half_hi, half_lo;
+        if (sh >= 64) {
+            mant = hi >> (sh - 64);
+            rem_hi = sh == 64 ? 0ull : (hi & ((1ull << (sh - 64)) - 1ull));
+            rem_lo = lo;
+        } else {
+            mant = (hi << (64 - sh)) | (lo >> sh);
+            rem_hi = 0ull;
+            rem_lo = lo & ((1ull << sh) - 1ull);
+        }
+        if (sh - 1 >= 64) { half_hi = 1ull << (sh - 1 - 64); half_lo = 0ull; }
+        else { half_hi = 0ull; half_lo = 1ull << (sh - 1); }
+        const bool gt = rem_hi > half_hi || (rem_hi == half_hi && rem_lo > half_lo);
+        const bool eq = rem_hi == half_hi && rem_lo == half_lo;
+        if (gt || (eq && (mant & 1ull))) mant += 1ull;
+        m = (double)mant;
+    }
+    const double v = __builtin_ldexp(m, sh - 64);
+    return neg ? -v : v;
 }
 
 // ---- device scene ----------------------------------------------------------------------------

@@ -1,16 +1,25 @@
 // rtw_hip.hip -- C ABI of librtw_hip.so (include/rtw_hip.h) over the gfx950 kernels.
 // Replaces /root/reference/src/render.jl:8-44 behind a ccall-able boundary.  No CPU fallback:
 // every compute entry point needs a HIP device and reports an error otherwise.
+//
+// Concurrency: every render call owns its own record (device counters + events) taken from a
+// mutex-guarded per-device pool, the trace kernel keeps all per-render state in LDS / registers
+// and there is no shared device workspace, so renders may be in flight concurrently on any mix
+// of streams, host threads and devices.  The caller's current HIP device is restored on return.
 #include "../../include/rtw_hip.h"
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "rtw_kernels.hpp"
@@ -35,45 +44,100 @@ int fail(int code, const char *fmt, ...) {
             return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-// ---- per-device context: cached workspace, counters, events ---------------------------------
+// restores the caller's current device when an entry point returns
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// ---- per-render record: device counters + the events that time the trace kernel ---------------
+struct RenderRec {
+    int device = -1;
+    rtw::DevCounters *ctr = nullptr;     // device memory
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool used = false;                   // ev1 has been recorded at least once
+    bool owned = false;                  // referenced by some thread's "last render"
+    int n_spheres = 0, n_chunks = 0, grid = 0;
+    ~RenderRec() {
+        if (ctr) (void)hipFree(ctr);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
+
 struct DeviceCtx {
     int device = -1;
-    double *partial = nullptr;
-    size_t partial_bytes = 0;
-    void *puv = nullptr;
-    size_t puv_bytes = 0;
-    rtw::DevCounters *ctr = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     int num_cus = 0;
-    // last render
-    bool pending = false;
-    uint64_t last_samples_expected = 0;
-    int last_n = 0, last_chunks = 0, last_grid = 0, last_block = 0;
+    std::mutex mu;
+    std::vector<std::unique_ptr<RenderRec>> recs;
 };
 
 std::mutex g_mu;
-std::vector<DeviceCtx *> g_ctx;
-thread_local DeviceCtx *g_last = nullptr;
+std::vector<std::unique_ptr<DeviceCtx>> g_ctx;
+std::atomic<unsigned> g_generation{1};      // bumped by rtw_shutdown: invalidates every thread's "last render"
+
+// what rtw_stats() reports: the records of the last render issued from this thread
+struct LastRender {
+    unsigned generation = 0;
+    bool resolved = false;
+    std::vector<RenderRec *> recs;          // pending (device-resident call) or already summed into `agg`
+    rtw_stats_t agg;
+};
+thread_local LastRender g_last;
 
 int get_ctx(int device, DeviceCtx **out) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (DeviceCtx *c : g_ctx)
-        if (c->device == device) { *out = c; return 0; }
-    DeviceCtx *c = new DeviceCtx();
+    for (auto &c : g_ctx)
+        if (c->device == device) { *out = c.get(); return 0; }
+    std::unique_ptr<DeviceCtx> c(new DeviceCtx());
     c->device = device;
-    HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(-20, "device %d is %s; librtw_hip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
     c->num_cus = prop.multiProcessorCount;
-    HIP_TRY(hipMalloc(&c->ctr, sizeof(rtw::DevCounters)));
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(hipEventCreate(&c->ev2));
-    g_ctx.push_back(c);
-    *out = c;
+    *out = c.get();
+    g_ctx.push_back(std::move(c));
     return 0;
+}
+
+// a record nobody references whose previous kernel (if any) has finished; the device must be current
+int acquire_rec(DeviceCtx *ctx, RenderRec **out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (auto &r : ctx->recs) {
+        if (r->owned) continue;
+        if (r->used && hipEventQuery(r->ev1) != hipSuccess) continue;
+        r->owned = true;
+        *out = r.get();
+        return 0;
+    }
+    std::unique_ptr<RenderRec> r(new RenderRec());
+    r->device = ctx->device;
+    HIP_TRY(hipMalloc(&r->ctr, sizeof(rtw::DevCounters)));
+    HIP_TRY(hipEventCreate(&r->ev0));
+    HIP_TRY(hipEventCreate(&r->ev1));
+    r->owned = true;
+    *out = r.get();
+    ctx->recs.push_back(std::move(r));
+    return 0;
+}
+
+void release_last() {
+    if (g_last.generation == g_generation.load()) {
+        for (RenderRec *r : g_last.recs) {
+            DeviceCtx *ctx = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(g_mu);
+                for (auto &c : g_ctx) if (c->device == r->device) ctx = c.get();
+            }
+            if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); r->owned = false; }
+        }
+    }
+    g_last.recs.clear();
+    g_last.resolved = false;
+    g_last.generation = g_generation.load();
+    memset(&g_last.agg, 0, sizeof g_last.agg);
 }
 
 int resolve_device(int device, int *out) {
@@ -104,6 +168,9 @@ struct rtw_scene_dev {
 };
 
 namespace {
+
+struct SceneDeleter { void operator()(rtw_scene_dev *h) const { rtw_scene_free(h); } };
+using ScenePtr = std::unique_ptr<rtw_scene_dev, SceneDeleter>;
 
 // kd median split of the small class into clusters of <= RTW_CULL_GS spheres (ids = indices into the caller's list)
 template <typename SceneT>
@@ -224,7 +291,11 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
         return fail(-1, "null scene array");
     for (int i = 0; i < s->n; ++i) {
         if (s->kind[i] < 0 || s->kind[i] > 2) return fail(-3, "sphere %d: unknown material kind %d", i, s->kind[i]);
+        if (!std::isfinite((double)s->cx[i]) || !std::isfinite((double)s->cy[i]) || !std::isfinite((double)s->cz[i]) ||
+            !std::isfinite((double)s->r[i]))
+            return fail(-3, "sphere %d: centre / radius is not finite", i);
     }
+    DeviceGuard guard;
     int dev;
     if (int rc = resolve_device(device, &dev)) return rc;
     DeviceCtx *ctx;
@@ -249,10 +320,9 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
             mat1[i] = V4{(T)0, (T)0, (T)0, (T)0};
         }
     }
-    rtw_scene_dev *h = new rtw_scene_dev();
+    ScenePtr h(new rtw_scene_dev());                      // freed on every error path below
+    memset(h.get(), 0, sizeof(rtw_scene_dev));
     h->device = dev; h->is_f64 = sizeof(T) == 8; h->n = n; h->n_pad = n_pad;
-    h->geom = h->mat0 = h->mat1 = nullptr;
-    h->c_bound = h->c_exact = h->c_mat0 = h->c_mat1 = nullptr; h->c_orig = nullptr;
     const size_t bytes = sizeof(V4) * (size_t)n_alloc;
     HIP_TRY(hipMalloc(&h->geom, bytes));
     HIP_TRY(hipMalloc(&h->mat0, bytes));
@@ -260,8 +330,8 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     HIP_TRY(hipMemcpy(h->geom, geom.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->mat0, mat0.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->mat1, mat1.data(), bytes, hipMemcpyHostToDevice));
-    if (int rc = build_cull<T>(s, h)) { rtw_scene_free(h); return rc; }
-    *out = h;
+    if (int rc = build_cull<T>(s, h.get())) return rc;
+    *out = h.release();
     return 0;
 }
 
@@ -283,7 +353,7 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
-    if (p->flags & ~RTW_FLAG_GROUP_CULL) return fail(-2, "unknown flags 0x%x", p->flags);
+    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES)) return fail(-2, "unknown flags 0x%x", p->flags);
     int nch = p->n_chunks > 0 ? p->n_chunks : (p->spp < 128 ? p->spp : 128);
     if (nch > p->spp) nch = p->spp;
     int cs = (p->spp + nch - 1) / nch;
@@ -292,8 +362,14 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     return 0;
 }
 
+long long local_tiles(const rtw_params *p) {
+    const long long n_tiles = (long long)((p->height + 7) / 8) * ((p->width + 7) / 8);
+    return n_tiles > p->shard_index ? (n_tiles - p->shard_index + p->shard_count - 1) / p->shard_count : 0;
+}
+
+// Enqueue one render (this shard's tiles) on `stream`; `rec` receives the counters and the kernel's events.
 template <typename T, typename CamT>
-int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, void *d_out, void *stream_v) {
+int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, void *d_out, hipStream_t stream, RenderRec **rec_out) {
     if (!scene || !cam || !d_out) return fail(-1, "null argument");
     if (scene->is_f64 != (sizeof(T) == 8)) return fail(-4, "scene handle precision does not match the call");
     int nch, cs;
@@ -303,43 +379,22 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     DeviceCtx *ctx;
     if (int rc = get_ctx(scene->device, &ctx)) return rc;
     HIP_TRY(hipSetDevice(scene->device));
-    hipStream_t stream = (hipStream_t)stream_v;
 
     rtw::KParams K;
+    memset(&K, 0, sizeof K);
     K.width = p->width; K.height = p->height; K.spp = p->spp; K.max_depth = p->max_depth;
     K.seed = p->seed; K.n_chunks = nch; K.chunk_spp = cs;
     K.shard_index = p->shard_index; K.shard_count = p->shard_count;
     K.tiles_i = (p->height + 7) / 8; K.tiles_j = (p->width + 7) / 8;
-    const long long n_tiles = (long long)K.tiles_i * K.tiles_j;
-    const long long n_local = n_tiles > p->shard_index ? (n_tiles - p->shard_index + p->shard_count - 1) / p->shard_count : 0;
-    const long long total_items = n_local * nch * 64;
-    if (total_items >= (1ll << 31)) return fail(-5, "render too large for one call: %lld work items", total_items);
-    K.n_local_tiles = (int)n_local; K.total_items = (unsigned)total_items; K.gamma = p->gamma;
-    make_udiv((unsigned)nch, &K.div_chunks_m, &K.div_chunks_s);
+    const long long n_local = local_tiles(p);
+    const long long total_jobs = n_local * 4;
+    const long long bpj = (nch + RTW_JOB_CPB - 1) / RTW_JOB_CPB;
+    if (total_jobs >= (1ll << 31) || total_jobs * bpj >= (1ll << 40))
+        return fail(-5, "render too large for one call: %lld pixel-block jobs", total_jobs);
+    K.total_jobs = (unsigned)total_jobs; K.bpj = (unsigned)bpj; K.gamma = p->gamma;
+    K.out_layout = (p->flags & RTW_FLAG_COMPACT_TILES) ? 1 : 0;
+    make_udiv((unsigned)bpj, &K.div_bpj_m, &K.div_bpj_s);
     make_udiv((unsigned)K.tiles_i, &K.div_tiles_m, &K.div_tiles_s);
-
-    // per-column / per-row (u, v) of src/render.jl:26-27: T(j / W) and T((H - i) / H), Float64 division
-    // then conversion, evaluated here on the host (exactly the arithmetic the reference performs)
-    {
-        std::vector<T> puv((size_t)p->width + p->height);
-        for (int j0 = 0; j0 < p->width; ++j0) puv[j0] = (T)((double)(j0 + 1) / (double)p->width);
-        for (int i0 = 0; i0 < p->height; ++i0) puv[(size_t)p->width + i0] = (T)((double)(p->height - (i0 + 1)) / (double)p->height);
-        const size_t pb = puv.size() * sizeof(T);
-        if (ctx->puv_bytes < pb) {
-            if (ctx->puv) { HIP_TRY(hipFree(ctx->puv)); ctx->puv = nullptr; ctx->puv_bytes = 0; }
-            HIP_TRY(hipMalloc(&ctx->puv, pb));
-            ctx->puv_bytes = pb;
-        }
-        HIP_TRY(hipMemcpyAsync(ctx->puv, puv.data(), pb, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));          // puv is a stack-local host buffer
-    }
-
-    const size_t need = (size_t)(total_items > 0 ? total_items : 1) * 3 * sizeof(double);
-    if (ctx->partial_bytes < need) {
-        if (ctx->partial) { HIP_TRY(hipFree(ctx->partial)); ctx->partial = nullptr; ctx->partial_bytes = 0; }
-        HIP_TRY(hipMalloc(&ctx->partial, need));
-        ctx->partial_bytes = need;
-    }
 
     rtw::Camera<T> C;
     for (int k = 0; k < 3; ++k) {
@@ -356,16 +411,17 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     // persistent grid: enough 256-thread blocks to fill every CU at the kernel's occupancy
     static const bool phase_profile = getenv("RTW_PHASE_PROFILE") != nullptr;   // debugging aid, not for timed runs
     const size_t list_bytes = (size_t)RTW_LIST_CAP * 256 * sizeof(unsigned short);
+    const size_t shared_bytes = (sizeof(rtw::WgShared<T>) + 15) / 16 * 16;
     const bool cull = (p->flags & RTW_FLAG_GROUP_CULL) != 0;
     const rtw::CullScene<T> CS = cull_scene_of<T>(scene);
     const size_t n_cull = (size_t)rtw::cull_exact_count(CS);
     const size_t geom_bytes = cull ? n_cull * sizeof(V4) + ((n_cull * sizeof(unsigned short) + 15) / 16) * 16
                                    : (size_t)(scene->n_pad + RTW_SPHERE_TAIL) * sizeof(V4);
     const bool lds_scene = geom_bytes <= RTW_LDS_SCENE_MAX_BYTES;
-    const size_t lds_bytes = list_bytes + (lds_scene ? geom_bytes : 0);
-    typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, rtw::CullScene<T>, const T *, double *, rtw::DevCounters *);
+    const size_t lds_bytes = list_bytes + shared_bytes + (lds_scene ? geom_bytes : 0);
+    typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, rtw::CullScene<T>, T *, rtw::DevCounters *);
     kern_t kern;
-    if (cull && phase_profile) kern = (kern_t)rtw::trace_kernel<T, true, true, true>;      // profiling aid: LDS path only
+    if (cull && phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true>;
     else if (cull) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true>;
     else if (phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, false> : (kern_t)rtw::trace_kernel<T, true, false, false>;
     else kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false> : (kern_t)rtw::trace_kernel<T, false, false, false>;
@@ -373,47 +429,164 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 256, lds_bytes));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     long long grid = (long long)ctx->num_cus * blocks_per_cu;
-    const long long max_useful = (total_items + 255) / 256;
+    const long long max_useful = (total_jobs * bpj + 3) / 4;          // one batch per wave, 4 waves per block
     if (grid > max_useful) grid = max_useful;
     if (grid < 1) grid = 1;
 
-    HIP_TRY(hipMemsetAsync(ctx->ctr, 0, sizeof(rtw::DevCounters), stream));
-    HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)p->width * p->height * 3 * sizeof(T), stream));
-    HIP_TRY(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, CS, (const T *)ctx->puv, ctx->partial, ctx->ctr);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev1, stream));
-    const unsigned n_pix_local = (unsigned)n_local * 64u;
-    if (n_pix_local > 0) {
-        hipLaunchKernelGGL(rtw::finalize_kernel<T>, dim3((n_pix_local + 255) / 256), dim3(256), 0, stream, K,
-                           (const double *)ctx->partial, (T *)d_out);
+    RenderRec *rec;
+    if (int rc = acquire_rec(ctx, &rec)) return rc;
+    *rec_out = rec;
+    rec->n_spheres = scene->n; rec->n_chunks = nch; rec->grid = (int)grid;
+    HIP_TRY(hipMemsetAsync(rec->ctr, 0, sizeof(rtw::DevCounters), stream));
+    // pixels of other shards read 0 in the full-frame layout (the sum over the shards is the image)
+    if (K.out_layout == 0 && p->shard_count > 1)
+        HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)p->width * p->height * 3 * sizeof(T), stream));
+    HIP_TRY(hipEventRecord(rec->ev0, stream));
+    if (total_jobs > 0) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, CS, (T *)d_out, rec->ctr);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(ctx->ev2, stream));
-    ctx->pending = true;
-    ctx->last_n = scene->n; ctx->last_chunks = nch; ctx->last_grid = (int)grid; ctx->last_block = 256;
-    g_last = ctx;
+    HIP_TRY(hipEventRecord(rec->ev1, stream));
+    rec->used = true;
     return 0;
+}
+
+// wait for a record's kernel and add its counters to `agg`
+int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipEventSynchronize(r->ev1));
+    float k_ms = 0;
+    HIP_TRY(hipEventElapsedTime(&k_ms, r->ev0, r->ev1));
+    rtw::DevCounters c;
+    HIP_TRY(hipMemcpy(&c, r->ctr, sizeof c, hipMemcpyDeviceToHost));
+    if (getenv("RTW_PHASE_PROFILE")) {
+        double tot = 0;
+        for (int k = 0; k < 6; ++k) tot += (double)c.phase[k];
+        fprintf(stderr, "[rtw phase profile] wave-cycles: pull %.1f%%  sample+scatter finish %.1f%%  scan-pass1/level1 %.1f%%  extract/level2 %.1f%%  resolve %.1f%%  shade %.1f%%  (total %.3g)\n",
+                100 * c.phase[0] / tot, 100 * c.phase[1] / tot, 100 * c.phase[2] / tot, 100 * c.phase[4] / tot,
+                100 * c.phase[5] / tot, 100 * c.phase[3] / tot, tot);
+    }
+    agg->samples += c.samples;
+    agg->segments += c.segments;
+    agg->sphere_tests += c.segments * (uint64_t)r->n_spheres;
+    agg->kernel_ms = std::max(agg->kernel_ms, (double)k_ms);
+    agg->total_ms = std::max(agg->total_ms, (double)k_ms);
+    agg->n_chunks = r->n_chunks;
+    agg->grid_blocks = std::max(agg->grid_blocks, r->grid);
+    agg->block_threads = 256;
+    return 0;
+}
+
+template <typename T, typename CamT>
+int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, void *d_out, void *stream_v) {
+    DeviceGuard guard;
+    if (p && p->n_devices > 1) return fail(-2, "the device-resident entry point renders on the scene's device only (n_devices = %d)", p->n_devices);
+    RenderRec *rec = nullptr;
+    release_last();
+    int rc = launch_render<T>(scene, cam, p, d_out, (hipStream_t)stream_v, &rec);
+    if (rec) g_last.recs.push_back(rec);       // (also on a late error: released by the next call)
+    return rc;
+}
+
+// one shard of a host-buffer render: upload, render, copy back.  layout 0 -> `out` is the full frame;
+// compact (multi-device) -> the shard's tiles are scattered into the full frame on the host.
+template <typename T, typename SceneT, typename CamT>
+int render_host_shard(const SceneT *scene, const CamT *cam, rtw_params p, T *out, bool compact, RenderRec **rec_out, char *err, size_t err_len) {
+    int rc = 0;
+    rtw_scene_handle h_raw = nullptr;
+    void *d_out = nullptr;
+    T *staging = nullptr;
+    hipStream_t stream = nullptr;
+    do {
+        if ((rc = upload_scene<T>(scene, p.device, &h_raw))) break;
+        hipError_t e = hipSetDevice(h_raw->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { rc = fail((int)e, "stream: %s", hipGetErrorString(e)); break; }
+        p.device = h_raw->device;
+        const long long n_local = local_tiles(&p);
+        const size_t elems = compact ? (size_t)n_local * 64 * 3 : (size_t)p.width * (size_t)p.height * 3;
+        if (compact) p.flags |= RTW_FLAG_COMPACT_TILES;
+        if (elems == 0) break;
+        if ((e = hipMalloc(&d_out, elems * sizeof(T))) != hipSuccess) { rc = fail((int)e, "hipMalloc(image) failed: %s", hipGetErrorString(e)); break; }
+        if ((rc = launch_render<T>(h_raw, cam, &p, d_out, stream, rec_out))) break;
+        if (!compact) {
+            e = hipMemcpyAsync(out, d_out, elems * sizeof(T), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) { rc = fail((int)e, "image D2H failed: %s", hipGetErrorString(e)); break; }
+        } else {
+            if ((e = hipHostMalloc((void **)&staging, elems * sizeof(T), hipHostMallocDefault)) != hipSuccess) { rc = fail((int)e, "hipHostMalloc failed: %s", hipGetErrorString(e)); break; }
+            e = hipMemcpyAsync(staging, d_out, elems * sizeof(T), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) { rc = fail((int)e, "shard D2H failed: %s", hipGetErrorString(e)); break; }
+            // tile-major compact shard -> column-major frame: tile k of this shard is global tile k*count + index
+            const int tiles_i = (p.height + 7) / 8;
+            for (long long k = 0; k < n_local; ++k) {
+                const long long t = k * p.shard_count + p.shard_index;
+                const int tj = (int)(t / tiles_i), ti = (int)(t % tiles_i);
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j0 = tj * 8 + jj;
+                    if (j0 >= p.width) break;
+                    const int rows = std::min(8, p.height - ti * 8);
+                    // 8 consecutive rows of one column are contiguous in both layouts
+                    memcpy(out + ((size_t)j0 * p.height + (size_t)ti * 8) * 3, staging + ((size_t)k * 64 + (size_t)jj * 8) * 3, (size_t)rows * 3 * sizeof(T));
+                }
+            }
+        }
+    } while (0);
+    if (rc && err) snprintf(err, err_len, "%s", g_err);
+    if (staging) (void)hipHostFree(staging);
+    if (d_out) (void)hipFree(d_out);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (h_raw) rtw_scene_free(h_raw);
+    return rc;
 }
 
 template <typename T, typename SceneT, typename CamT>
 int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *out) {
     if (!scene || !cam || !p || !out) return fail(-1, "null argument");
-    rtw_scene_handle h = nullptr;
-    int rc = upload_scene<T>(scene, p->device, &h);
-    if (rc) return rc;
-    void *d_out = nullptr;
-    const size_t bytes = (size_t)p->width * (size_t)p->height * 3 * sizeof(T);
-    hipError_t e = (p->width > 0 && p->height > 0) ? hipMalloc(&d_out, bytes) : hipSuccess;
-    if (e != hipSuccess) { rtw_scene_free(h); return fail((int)e, "hipMalloc(image) failed: %s", hipGetErrorString(e)); }
-    rc = d_out ? render_device<T>(h, cam, p, d_out, nullptr) : fail(-2, "width/height must be positive");
-    if (!rc) {
-        e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);   // blocking: waits for the render
-        if (e != hipSuccess) rc = fail((int)e, "hipMemcpy(image D2H) failed: %s", hipGetErrorString(e));
+    int nch, cs;
+    if (int rc = validate_params(p, &nch, &cs)) return rc;
+    DeviceGuard guard;
+    release_last();
+    // the device list (n_devices / device_ids; Julia keyword devices=:all)
+    std::vector<int> devs;
+    if (p->n_devices == -1) {
+        int n = 0;
+        HIP_TRY(hipGetDeviceCount(&n));
+        for (int d = 0; d < n; ++d) devs.push_back(d);
+        if (devs.empty()) return fail(-21, "no HIP device available; librtw_hip has no CPU fallback");
+    } else if (p->n_devices > 1) {
+        if (!p->device_ids) return fail(-1, "n_devices = %d but device_ids is null", p->n_devices);
+        devs.assign(p->device_ids, p->device_ids + p->n_devices);
+    } else if (p->n_devices < -1) {
+        return fail(-2, "bad n_devices %d", p->n_devices);
     }
-    if (d_out) hipFree(d_out);
-    rtw_scene_free(h);
-    return rc;
+    if (devs.size() <= 1) {
+        rtw_params q = *p;
+        if (devs.size() == 1) q.device = devs[0];
+        RenderRec *rec = nullptr;
+        int rc = render_host_shard<T>(scene, cam, q, out, false, &rec, nullptr, 0);
+        if (rec) g_last.recs.push_back(rec);
+        return rc;
+    }
+    if (p->shard_count != 1) return fail(-2, "n_devices > 1 cannot be combined with shard_index/shard_count");
+    // one host thread per device renders tiles t = r (mod N) and scatters them into `out`; tiles are disjoint
+    const int N = (int)devs.size();
+    std::vector<int> rcs(N, 0);
+    std::vector<RenderRec *> recs(N, nullptr);
+    std::vector<std::vector<char>> errs(N, std::vector<char>(512, 0));
+    std::vector<std::thread> th;
+    for (int r = 0; r < N; ++r) {
+        th.emplace_back([&, r]() {
+            rtw_params q = *p;
+            q.device = devs[r]; q.shard_index = r; q.shard_count = N; q.n_devices = 0; q.device_ids = nullptr;
+            rcs[r] = render_host_shard<T>(scene, cam, q, out, true, &recs[r], errs[r].data(), errs[r].size());
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int r = 0; r < N; ++r) if (recs[r]) g_last.recs.push_back(recs[r]);
+    for (int r = 0; r < N; ++r) if (rcs[r]) return fail(rcs[r], "device %d (shard %d of %d): %s", devs[r], r, N, errs[r].data());
+    return 0;
 }
 
 // T0 unit entry point: host slots -> device -> unit_kernel -> host slots
@@ -422,21 +595,27 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
     if (op < 0 || op >= rtw::U_NUM_OPS) return fail(-2, "unknown unit op %d", op);
     if (count < 0 || (count > 0 && (!in || !out))) return fail(-1, "null argument");
     if (count == 0) return 0;
-    const bool needs_scene = op == rtw::U_HIT_WORLD || op == rtw::U_RAY_COLOR;
+    const bool needs_scene = op == rtw::U_HIT_WORLD || op == rtw::U_RAY_COLOR || op == rtw::U_HIT_WORLD_LDS || op == rtw::U_HIT_WORLD_CULL;
     if (needs_scene && !scene) return fail(-1, "op %d needs a scene", op);
     if (op == rtw::U_GET_RAY && !cam) return fail(-1, "op %d needs a camera", op);
+    DeviceGuard guard;
     int dev;
     if (int rc = resolve_device(-1, &dev)) return rc;
     DeviceCtx *ctx;
     if (int rc = get_ctx(dev, &ctx)) return rc;
-    rtw_scene_handle h = nullptr;
+    rtw_scene_handle h_raw = nullptr;
     rtw::DevScene<T> S{nullptr, nullptr, nullptr, 0, 0};
+    rtw::CullScene<T> CS;
+    memset(&CS, 0, sizeof CS);
     if (needs_scene) {
-        if (int rc = upload_scene<T>(scene, dev, &h)) return rc;
+        if (int rc = upload_scene<T>(scene, dev, &h_raw)) return rc;
         using V4 = typename rtw::Vec4<T>::type;
-        S.geom = (const V4 *)h->geom; S.mat0 = (const V4 *)h->mat0; S.mat1 = (const V4 *)h->mat1;
-        S.n = h->n; S.n_pad = h->n_pad;
+        S.geom = (const V4 *)h_raw->geom; S.mat0 = (const V4 *)h_raw->mat0; S.mat1 = (const V4 *)h_raw->mat1;
+        S.n = h_raw->n; S.n_pad = h_raw->n_pad;
+        CS = cull_scene_of<T>(h_raw);
     }
+    ScenePtr h(h_raw);
+    HIP_TRY(hipSetDevice(dev));
     rtw::Camera<T> C;
     memset(&C, 0, sizeof C);
     if (cam) {
@@ -447,6 +626,14 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
         }
         C.lens_radius = cam->lens_radius;
     }
+    using V4 = typename rtw::Vec4<T>::type;
+    size_t lds_bytes = 0;
+    if (op == rtw::U_HIT_WORLD_LDS) lds_bytes = (size_t)(S.n_pad + RTW_SPHERE_TAIL) * sizeof(V4);
+    if (op == rtw::U_HIT_WORLD_CULL) {
+        const size_t n_cull = (size_t)rtw::cull_exact_count(CS);
+        lds_bytes = n_cull * sizeof(V4) + ((n_cull * sizeof(unsigned short) + 15) / 16) * 16;
+    }
+    if (lds_bytes > 60 * 1024) return fail(-5, "scene too large for the LDS-staged unit op %d (%zu bytes)", op, lds_bytes);
     const size_t in_b = (size_t)count * rtw::unit_in_slots(op) * 8, out_b = (size_t)count * rtw::unit_out_slots(op) * 8;
     double *d_in = nullptr, *d_out = nullptr;
     int rc = 0;
@@ -455,13 +642,12 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
         (e = hipMemcpy(d_in, in, in_b, hipMemcpyHostToDevice)) != hipSuccess) {
         rc = fail((int)e, "unit buffers: %s", hipGetErrorString(e));
     } else {
-        hipLaunchKernelGGL(rtw::unit_kernel<T>, dim3((count + 63) / 64), dim3(64), 0, 0, op, count, d_in, d_out, S, C);
+        hipLaunchKernelGGL(rtw::unit_kernel<T>, dim3((count + 63) / 64), dim3(64), lds_bytes, 0, op, count, d_in, d_out, S, CS, C);
         if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost)) != hipSuccess)
             rc = fail((int)e, "unit kernel: %s", hipGetErrorString(e));
     }
-    if (d_in) hipFree(d_in);
-    if (d_out) hipFree(d_out);
-    if (h) rtw_scene_free(h);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
     return rc;
 }
 
@@ -487,15 +673,10 @@ int rtw_scene_upload_f64(const rtw_scene_f64 *s, int device, rtw_scene_handle *o
 
 int rtw_scene_free(rtw_scene_handle h) {
     if (!h) return 0;
-    hipSetDevice(h->device);
-    if (h->geom) hipFree(h->geom);
-    if (h->c_bound) hipFree(h->c_bound);
-    if (h->c_exact) hipFree(h->c_exact);
-    if (h->c_mat0) hipFree(h->c_mat0);
-    if (h->c_mat1) hipFree(h->c_mat1);
-    if (h->c_orig) hipFree(h->c_orig);
-    if (h->mat0) hipFree(h->mat0);
-    if (h->mat1) hipFree(h->mat1);
+    DeviceGuard guard;
+    (void)hipSetDevice(h->device);
+    void *ptrs[] = {h->geom, h->mat0, h->mat1, h->c_bound, h->c_exact, h->c_mat0, h->c_mat1, h->c_orig};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
     delete h;
     return 0;
 }
@@ -515,31 +696,16 @@ int rtw_render_f64(const rtw_scene_f64 *s, const rtw_camera_f64 *c, const rtw_pa
 
 int rtw_stats(rtw_stats_t *out) {
     if (!out) return fail(-1, "null argument");
-    DeviceCtx *ctx = g_last;
-    if (!ctx) return fail(-6, "no render has been issued from this thread");
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipEventSynchronize(ctx->ev2));
-    float k_ms = 0, t_ms = 0;
-    HIP_TRY(hipEventElapsedTime(&k_ms, ctx->ev0, ctx->ev1));
-    HIP_TRY(hipEventElapsedTime(&t_ms, ctx->ev0, ctx->ev2));
-    rtw::DevCounters c;
-    HIP_TRY(hipMemcpy(&c, ctx->ctr, sizeof c, hipMemcpyDeviceToHost));
-    if (getenv("RTW_PHASE_PROFILE")) {
-        double tot = 0;
-        for (int k = 0; k < 6; ++k) tot += (double)c.phase[k];
-        fprintf(stderr, "[rtw phase profile] wave-cycles: pull %.1f%%  raygen %.1f%%  scan-pass1/level1 %.1f%%  extract/level2 %.1f%%  resolve %.1f%%  shade %.1f%%  (total %.3g)\n",
-                100 * c.phase[0] / tot, 100 * c.phase[1] / tot, 100 * c.phase[2] / tot, 100 * c.phase[4] / tot,
-                100 * c.phase[5] / tot, 100 * c.phase[3] / tot, tot);
+    if (g_last.generation != g_generation.load() || (g_last.recs.empty() && !g_last.resolved))
+        return fail(-6, "no render has been issued from this thread");
+    DeviceGuard guard;
+    if (!g_last.resolved) {
+        memset(&g_last.agg, 0, sizeof g_last.agg);
+        for (RenderRec *r : g_last.recs)
+            if (int rc = resolve_rec(r, &g_last.agg)) return rc;
+        g_last.resolved = true;
     }
-    memset(out, 0, sizeof *out);
-    out->samples = c.samples;
-    out->segments = c.segments;
-    out->sphere_tests = c.segments * (uint64_t)ctx->last_n;
-    out->kernel_ms = k_ms;
-    out->total_ms = t_ms;
-    out->n_chunks = ctx->last_chunks;
-    out->grid_blocks = ctx->last_grid;
-    out->block_threads = ctx->last_block;
+    *out = g_last.agg;
     return 0;
 }
 
@@ -551,19 +717,15 @@ int rtw_unit_f64(int op, int count, const void *in, void *out, const rtw_scene_f
 }
 
 int rtw_shutdown(void) {
+    DeviceGuard guard;
     std::lock_guard<std::mutex> lk(g_mu);
-    for (DeviceCtx *c : g_ctx) {
-        hipSetDevice(c->device);
-        if (c->partial) hipFree(c->partial);
-        if (c->puv) hipFree(c->puv);
-        if (c->ctr) hipFree(c->ctr);
-        if (c->ev0) hipEventDestroy(c->ev0);
-        if (c->ev1) hipEventDestroy(c->ev1);
-        if (c->ev2) hipEventDestroy(c->ev2);
-        delete c;
+    g_generation.fetch_add(1);                 // every thread's "last render" is now stale (rtw_stats reports -6)
+    for (auto &c : g_ctx) {
+        (void)hipSetDevice(c->device);
+        std::lock_guard<std::mutex> lk2(c->mu);
+        c->recs.clear();
     }
     g_ctx.clear();
-    g_last = nullptr;
     return 0;
 }
 

@@ -1,21 +1,33 @@
-// rtw_kernels.hpp -- the trace kernel (render -> ray_color -> hit/scatter fused) and the
-// finalize kernel.  gfx950 only; wave = 64 lanes.
+// rtw_kernels.hpp -- the trace kernel: render -> ray_color -> hit/scatter fused, including the
+// pixel accumulation and the gamma / store of src/render.jl:40.  gfx950 only; wave = 64 lanes.
 //
 // Work decomposition
-//   item  = (pixel, sample chunk): `chunk_spp` consecutive samples of one pixel drawn from the
-//           item's own Xoroshiro128+ stream.  Items are enumerated tile-major: 64 consecutive
-//           items are one 8x8 pixel tile for one chunk, so a wave starts out coherent.
-//   lane  = persistent worker.  It owns one item at a time, regenerates a camera ray the moment
-//           its path ends (no lock-step with the other lanes' path lengths), and pulls the next
-//           item from a global queue when its chunk is finished.  The only convergent part is
-//           the sphere scan, which every live lane executes every iteration.
-//   out   = per-item chunk sums (3 doubles) -> finalize kernel adds them in chunk order, divides
-//           by spp, applies gamma and stores RGB{T}.  Results do not depend on scheduling, grid
-//           size or shard count.
+//   job   = one 4x4 pixel block (a quarter of an 8x8 tile) for ALL its sample chunks.  Jobs come
+//           from one global queue (one atomic per job); a job is owned by ONE workgroup, whose
+//           LDS holds the block's 16 x 3 pixel accumulators while the job is in flight.
+//   item  = (pixel, chunk): `chunk_spp` consecutive samples of one pixel drawn from the item's own
+//           Xoroshiro128+ stream.  64 consecutive items = 16 pixels x 4 chunks = one wave batch,
+//           taken from the workgroup's ticket counter in LDS.
+//   lane  = persistent worker.  It owns one item at a time, starts its next sample the moment
+//           its path ends (no lock-step on path length) and takes the next item when its chunk
+//           is finished.  The only convergent part is the sphere scan, which every lane with a
+//           ray executes every iteration.
+//   accum = a finished chunk sum (3 doubles) is added to the job's accumulators EXACTLY (64.64
+//           fixed point, LDS integer atomics) -- addition order does not matter, so there is no
+//           per-chunk workspace in HBM and no second kernel: the lane that retires the job's last
+//           item triggers the store of the 16 pixels (sum -> / spp -> sqrt -> RGB{T}).
+//   Results do not depend on scheduling, grid size, shard count or job-slot availability.
 #pragma once
 #include "rtw_device.hpp"
 
 namespace rtw {
+
+#define RTW_JOB_PX 16        // pixels per job (4x4 block)
+#define RTW_JOB_CPB 4        // chunks per 64-item batch
+#define RTW_NSLOT 6          // jobs in flight per workgroup
+#define RTW_SLOT_FREE 0xffffffffu
+#define RTW_SLOT_OPENING 0xfffffffeu
+#define RTW_JOB_EOF 0xffffffffu
 
 struct KParams {
     int width, height, spp, max_depth;
@@ -24,19 +36,36 @@ struct KParams {
     int chunk_spp;
     int shard_index, shard_count;
     int tiles_i, tiles_j;  // 8x8 tiles along rows (i) and columns (j)
-    int n_local_tiles;
-    unsigned total_items;  // n_local_tiles * n_chunks * 64
-    // exact unsigned division by the two loop-invariant divisors of the item decode (host: make_udiv):
+    unsigned total_jobs;   // 4 * (tiles owned by this shard)
+    unsigned bpj;          // batches per job = ceil(n_chunks / RTW_JOB_CPB)
+    // exact unsigned division by loop-invariant divisors (host: make_udiv):
     // n / d == (umulhi(n, m) + ((n - umulhi(n, m)) >> 1)) >> s   for every 32-bit n
-    unsigned div_chunks_m, div_chunks_s, div_tiles_m, div_tiles_s;
+    unsigned div_bpj_m, div_bpj_s, div_tiles_m, div_tiles_s;
     int gamma;
+    int out_layout;        // 0: Matrix{RGB{T}} column-major full frame; 1: compact, tile-major, this shard only
 };
 
 struct DevCounters {
-    unsigned long long next_item;
+    unsigned next_job;
+    unsigned pad;
     unsigned long long segments;
     unsigned long long samples;
     unsigned long long phase[8];   // RTW_PHASE_PROFILE=1 only: wave-cycles per phase (s_memtime)
+};
+
+// One job in flight: the 16 pixels' accumulators and the bookkeeping of the open/retire protocol.
+struct JobSlot {
+    unsigned long long acc[RTW_JOB_PX][7];   // r.lo r.hi g.lo g.hi b.lo b.hi poison
+    unsigned ready_seq;                      // RTW_SLOT_FREE | RTW_SLOT_OPENING | the job sequence number it holds
+    unsigned job;                            // global job id, or RTW_JOB_EOF (queue exhausted; never freed)
+    int remaining;                           // items of the job not yet added
+    unsigned pad;
+};
+template <typename T> struct WgShared {
+    JobSlot slot[RTW_NSLOT];
+    unsigned ticket;                         // next batch of this workgroup
+    unsigned pad[3];
+    Camera<T> cam;                           // read per new sample (keeps 22 SGPRs out of the scan loop)
 };
 
 // Phase profiler (opt-in instantiation, never used for timed runs): s_memtime stamps around
@@ -56,144 +85,110 @@ __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned 
 }
 
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ unsigned uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
+// (i0, j0) of pixel `px` (0..15) of job `job`: job = 4 * (local tile) + quadrant
+__device__ __forceinline__ void job_pixel(const KParams &P, unsigned job, unsigned px, int &i0, int &j0, unsigned &k) {
+    k = job >> 2;
+    const unsigned q = job & 3u;
+    const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
+    const unsigned tj = udiv_magic(t, P.div_tiles_m, P.div_tiles_s), ti = t - tj * (unsigned)P.tiles_i;
+    i0 = (int)(ti * 8u + (q & 1u) * 4u + (px & 3u));
+    j0 = (int)(tj * 8u + (q >> 1) * 4u + (px >> 2));
+}
 
 // waves per SIMD the trace kernel is compiled for (second __launch_bounds__ argument):
 // Float32 -> 7 (VGPR cap 72), Float64 -> 4 (cap 128; the double state does not fit lower caps)
 #ifndef RTW_TRACE_WAVES_F32
 #define RTW_TRACE_WAVES_F32 7
 #endif
+#ifndef RTW_TRACE_WAVES_F64
+#define RTW_TRACE_WAVES_F64 4
+#endif
 template <typename T> struct TraceWaves { static constexpr int value = RTW_TRACE_WAVES_F32; };
-template <> struct TraceWaves<double> { static constexpr int value = 4; };
-// the group-cull variant keeps the slab-test constants live across the scan: fewer waves, no spills
+template <> struct TraceWaves<double> { static constexpr int value = RTW_TRACE_WAVES_F64; };
+// the group-cull variant keeps the slab-test constants live across the scan: fewer waves
 #ifndef RTW_TRACE_WAVES_CULL_F32
 #define RTW_TRACE_WAVES_CULL_F32 5
 #endif
 template <typename T, bool CULL> struct TraceWavesOf { static constexpr int value = TraceWaves<T>::value; };
 template <> struct TraceWavesOf<float, true> { static constexpr int value = RTW_TRACE_WAVES_CULL_F32; };
 template <> struct TraceWavesOf<double, true> { static constexpr int value = 3; };
-#ifndef RTW_ITEM_BATCH
-#define RTW_ITEM_BATCH 64u   // work items a wave takes from the global queue per atomic
-#endif
+
+// The store of one finished job (src/render.jl:40, src/vec.jl:22): lane = (pixel, channel).
+template <typename T>
+__device__ __forceinline__ void store_job(const KParams &P, const JobSlot *S, unsigned job, unsigned lane, T *__restrict__ out) {
+    if (lane < 3u * RTW_JOB_PX) {
+        const unsigned px = lane & (RTW_JOB_PX - 1u), ch = lane >> 4;
+        int i0, j0; unsigned k;
+        job_pixel(P, job, px, i0, j0, k);
+        if (i0 < P.height && j0 < P.width) {
+            double v = fx_to_double(S->acc[px][2 * ch], S->acc[px][2 * ch + 1]);
+            if (S->acc[px][6] != 0ull) v = __builtin_nan("");
+            v = v / (double)P.spp;
+            if (P.gamma) v = __builtin_sqrt(v);
+            const size_t pix = P.out_layout == 0 ? (size_t)j0 * (size_t)P.height + (size_t)i0
+                                                 : (size_t)k * 64u + (size_t)((i0 & 7) + 8 * (j0 & 7));
+            out[pix * 3 + ch] = (T)v;
+        }
+    }
+}
 
 template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL>
-__global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_kernel(KParams P, Camera<T> cam, DevScene<T> scene,
-                                                   CullScene<T> cull, const T *__restrict__ puv,
-                                                   double *__restrict__ partial, DevCounters *ctr) {
+__global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_kernel(KParams P, Camera<T> cam_arg, DevScene<T> scene,
+                                                   CullScene<T> cull, T *__restrict__ out, DevCounters *ctr) {
     using V4 = typename Vec4<T>::type;
     const unsigned lane = lane_id();
-    // LDS: [per-lane candidate lists, stride 256][scene geom copy (LDS_SCENE only)]
+    // LDS: [per-lane candidate lists, stride 256][job slots, ticket, camera][scene geom copy (LDS_SCENE only)]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short *my_list = reinterpret_cast<unsigned short *>(smem) + threadIdx.x;
-    V4 *lds_geom = reinterpret_cast<V4 *>(smem + RTW_LIST_CAP * 256 * sizeof(unsigned short));
+    constexpr size_t list_bytes = RTW_LIST_CAP * 256 * sizeof(unsigned short);
+    constexpr size_t shared_bytes = (sizeof(WgShared<T>) + 15) / 16 * 16;
+    WgShared<T> *sh = reinterpret_cast<WgShared<T> *>(smem + list_bytes);
+    V4 *lds_geom = reinterpret_cast<V4 *>(smem + list_bytes + shared_bytes);
     unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + (CULL ? cull_exact_count(cull) : 0));
+    if (threadIdx.x < RTW_NSLOT) { sh->slot[threadIdx.x].ready_seq = RTW_SLOT_FREE; sh->slot[threadIdx.x].job = 0u; }
+    if (threadIdx.x == 0) { sh->ticket = 0u; sh->cam = cam_arg; }
     if (LDS_SCENE) {
         if (CULL) stage_cull_scene<T>(cull, lds_geom, lds_orig);
         else stage_scene<T>(scene, lds_geom);
-        __syncthreads();
     }
-    // the wave's local pool of work items [pool_next, pool_end): one global atomic per batch
-    unsigned pool_next = 0, pool_end = 0;
+    __syncthreads();
+
+    // ---- wave-uniform state ----
+    unsigned pool_next = 0, pool_end = 0;   // unassigned items [pool_next, pool_end) of the wave's current batch
+    unsigned pool_slot = 0, pool_job = 0, pool_b = 0;
+    bool have_ticket = false;               // a batch ticket drawn but not yet usable (its job slot is not open)
+    unsigned tk_seq = 0, tk_b = 0;
+    unsigned long long n_segments = 0, n_samples = 0;
 
     // ---- per-lane state ----
     bool alive = true;        // still pulling work
-    bool have_item = false;   // owns an item whose chunk sum is not yet flushed
-    bool has_ray = false;     // a path is in flight
-    unsigned item_slot = 0;   // where the chunk sum goes: (local pixel)*n_chunks + chunk
+    bool have_item = false;   // owns an item whose chunk sum is not yet added
+    bool has_ray = false;     // a ray is ready for the scan
+    int todo = PATH_READY;    // PATH_BALL: scatter waits for a unit-ball sample; PATH_NORM: direction to normalise
+    bool new_sample = false;  // camera ray under construction (waits for a unit-disk sample)
+    unsigned item_ref = 0;    // slot * 16 + pixel of the owned item
     int samples_left = 0;
     int s_global = 0;         // 0-based sample index within the pixel (sample 0 is un-jittered)
-    T pu = 0, pv = 0;         // pixel's (u, v)  (src/render.jl:26-27)
+    T pu = 0, pv = 0;         // pixel's (u, v)  (src/render.jl:26-27), then (u + du, v + dv) of the sample
     Rng rng = {1, 2};
     double acc_r = 0, acc_g = 0, acc_b = 0;
     V3<T> ro = {0, 0, 0}, rd = {0, 0, 1};
+    V3<T> vec = {0, 0, 0};    // PATH_BALL: n (Lambertian) / reflect(d, n) (Metal); PATH_NORM: the raw direction
+    T vscale_ = 1;            // PATH_BALL: 1 (Lambertian) / fuzz (Metal)
+    int kind = 0;
+    T su = 0, sv = 0;
     double thr_r = 1, thr_g = 1, thr_b = 1;
     int depth_left = 0;
-    unsigned my_segments = 0, my_samples = 0;
 
-    const T inv_w_div = (T)(float)P.width;   // f32_image_width  (src/render.jl:16)
-    const T inv_h_div = (T)(float)P.height;  // f32_image_height (src/render.jl:17)
+    const T w_div = (T)(float)P.width;    // f32_image_width  (src/render.jl:16)
+    const T h_div = (T)(float)P.height;   // f32_image_height (src/render.jl:17)
 
     PhaseClock<PROFILE> clk;
     for (;;) {
         clk.start();
-        // ---- (A) lanes whose chunk is done flush it and pull the next item ----
-        const bool need = alive && !has_ray && samples_left == 0;
-        const unsigned long long need_mask = __ballot(need);
-        if (need_mask) {
-            const unsigned cnt = __popcll(need_mask);
-            const unsigned avail = pool_end - pool_next;
-            unsigned new_base = 0;
-            if (cnt > avail) {                                   // wave-uniform: refill the pool
-                unsigned long long got = 0;
-                if (lane == 0) got = atomicAdd(&ctr->next_item, (unsigned long long)RTW_ITEM_BATCH);
-                got = __shfl(got, 0);
-                new_base = got > 0xffffffffull ? 0xffffffffu : (unsigned)got;   // beyond total_items anyway
-            }
-            if (need) {
-                if (have_item) {
-                    double *dst = partial + (size_t)item_slot * 3;
-                    dst[0] = acc_r; dst[1] = acc_g; dst[2] = acc_b;
-                    have_item = false;
-                }
-                const unsigned rank = __popcll(need_mask & ((1ull << lane) - 1ull));
-                const unsigned long long idx = rank < avail ? (unsigned long long)pool_next + rank
-                                                            : (unsigned long long)new_base + (rank - avail);
-                if (idx >= P.total_items) {
-                    alive = false;
-                } else {
-                    // idx = (k * n_chunks + chunk) * 64 + pl
-                    const unsigned pl = (unsigned)idx & 63u, q = (unsigned)idx >> 6;
-                    const unsigned k = udiv_magic(q, P.div_chunks_m, P.div_chunks_s);      // local tile
-                    const unsigned chunk = q - k * (unsigned)P.n_chunks;
-                    const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
-                    const int tj = (int)udiv_magic(t, P.div_tiles_m, P.div_tiles_s), ti = (int)(t - (unsigned)tj * (unsigned)P.tiles_i);
-                    const int i0 = ti * 8 + (int)(pl & 7u), j0 = tj * 8 + (int)(pl >> 3);  // 0-based
-                    if (i0 < P.height && j0 < P.width) {
-                        const int i = i0 + 1, j = j0 + 1;                // Julia's 1-based (i, j)
-                        pu = puv[j0];                                    // T(j / W),       src/render.jl:26
-                        pv = puv[P.width + i0];                          // T((H - i) / H), src/render.jl:27
-                        (void)i; (void)j;
-                        const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
-                        rng_stream(P.seed, pix, chunk, rng);
-                        s_global = (int)chunk * P.chunk_spp;
-                        const int s_end = min(P.spp, s_global + P.chunk_spp);
-                        samples_left = s_end - s_global;
-                        item_slot = (k * 64u + pl) * (unsigned)P.n_chunks + chunk;
-                        acc_r = acc_g = acc_b = 0.0;
-                        have_item = true;
-                    }
-                    // out-of-image pixel of an edge tile: nothing to do, pull again next round
-                }
-            }
-            if (cnt > avail) {
-                pool_next = new_base + (cnt - avail);
-                pool_end = new_base > 0xffffffffu - RTW_ITEM_BATCH ? 0xffffffffu : new_base + RTW_ITEM_BATCH;
-                if (pool_next > pool_end) pool_next = pool_end;
-            } else {
-                pool_next += cnt;
-            }
-        }
-        if (!__any(alive)) break;
-        clk.lap(0);
-
-        // ---- (B) start the next sample (src/render.jl:29-37) ----
-        if (alive && !has_ray && samples_left > 0) {
-            T du = 0, dv = 0;
-            if (s_global != 0) {
-                T r1, r2;
-                trand(rng, r1); du = r1 / inv_w_div;
-                trand(rng, r2); dv = r2 / inv_h_div;
-            }
-            get_ray(rng, cam, pu + du, pv + dv, ro, rd);
-            thr_r = thr_g = thr_b = 1.0;
-            depth_left = P.max_depth;
-            has_ray = depth_left > 0;    // depth <= 0: ray_color returns 0 (src/ray_color.jl:15)
-            samples_left -= 1;
-            s_global += 1;
-            my_samples += 1;
-        }
-
-        clk.lap(1);
-        // ---- (C) closest hit over the whole sphere list (src/hit.jl:38-50) ----
+        // ---- (S) closest hit over the whole sphere list (src/hit.jl:38-50) ----
         T t_hit = 0;
         int idx = -1;
         if (has_ray) {
@@ -206,62 +201,211 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
                 idx = hit_world<T, 256>(scene, (const V4 *)lds_geom, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list, clk);
             else
                 idx = hit_world<T, 256>(scene, scene.geom, ro, rd, (T)1e-4, (T)__builtin_huge_val(), t_hit, my_list, clk);
-            my_segments += 1;
         }
-
+        n_segments += (unsigned long long)__popcll(__ballot(has_ray));
         clk.lap(2);
-        // ---- (D) shade (src/ray_color.jl:20-37) ----
+
+        // ---- (H) shade (src/ray_color.jl:20-37): sky ends the sample; a hit starts the scatter ----
         if (has_ray) {
+            has_ray = false;
             if (idx < 0) {
                 const C3 sky = skycolor(rd);
                 acc_r += thr_r * sky.r; acc_g += thr_g * sky.g; acc_b += thr_b * sky.b;
-                has_ray = false;
             } else {
-                const typename Vec4<T>::type g = CULL ? cull.exact[idx] : scene.geom[idx];    // CULL: device order
-                const typename Vec4<T>::type m0 = CULL ? cull.mat0[idx] : scene.mat0[idx];
-                const typename Vec4<T>::type m1 = CULL ? cull.mat1[idx] : scene.mat1[idx];
+                const V4 g = CULL ? cull.exact[idx] : scene.geom[idx];    // CULL: device order
+                const V4 m0 = CULL ? cull.mat0[idx] : scene.mat0[idx];
+                const V4 m1 = CULL ? cull.mat1[idx] : scene.mat1[idx];
                 HitRec<T> rec;
                 make_hitrec<T>({g.x, g.y, g.z}, m0.x, ro, rd, t_hit, rec);
-                V3<T> nd, att;
-                scatter<T>(rng, (int)m0.z, {m1.x, m1.y, m1.z}, m0.y, rd, rec, nd, att);
+                kind = (int)m0.z;
+                todo = scatter_begin<T>(rng, kind, m0.y, rd, rec, vec, vscale_);
+                const V3<T> att = attenuation_of<T>(kind, {m1.x, m1.y, m1.z});
                 thr_r = thr_r * (double)att.x; thr_g = thr_g * (double)att.y; thr_b = thr_b * (double)att.z;
-                ro = rec.p; rd = nd;
+                ro = rec.p;
                 depth_left -= 1;
-                if (depth_left <= 0) has_ray = false;   // recursion bottoms out with 0 radiance
+                if (todo == PATH_READY) { rd = vec; has_ray = depth_left > 0; }   // depth 0: ray_color returns 0
             }
         }
         clk.lap(3);
+
+        // ---- (A) lanes whose chunk is done add it to their job, retire jobs, take the next item ----
+        const bool idle = alive && !has_ray && todo == PATH_READY;           // no path in flight
+        const bool need = idle && samples_left == 0;
+        const unsigned long long need_mask = __ballot(need);
+        if (need_mask) {
+            bool last = false;
+            if (need && have_item) {
+                JobSlot *S = &sh->slot[item_ref >> 4];
+                unsigned long long *a = S->acc[item_ref & 15u];
+                const double cs[3] = {acc_r, acc_g, acc_b};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    unsigned long long lo, hi;
+                    if (fx_from_double(cs[c], lo, hi)) {
+                        const unsigned long long old = __hip_atomic_fetch_add(&a[2 * c], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        hi += (old + lo < old) ? 1ull : 0ull;
+                        if (hi) __hip_atomic_fetch_add(&a[2 * c + 1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        __hip_atomic_fetch_add(&a[6], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                last = __hip_atomic_fetch_add(&S->remaining, -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
+                have_item = false;
+            }
+            // jobs whose last item was just added: the wave stores their 16 pixels and frees the slot
+            unsigned long long fin = __ballot(last);
+            while (fin) {
+                const int L = __builtin_ctzll(fin);
+                fin &= fin - 1ull;
+                const unsigned sl = uniform((unsigned)__shfl((int)(item_ref >> 4), L));
+                JobSlot *S = &sh->slot[sl];
+                const unsigned job = uniform(S->job);
+                store_job<T>(P, S, job, lane, out);
+                __hip_atomic_store(&S->ready_seq, RTW_SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // a wave without unassigned items draws a batch ticket and tries to make it usable
+            if (pool_next >= pool_end) {
+                if (!have_ticket) {
+                    unsigned t = 0;
+                    if (lane == 0) t = __hip_atomic_fetch_add(&sh->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    t = uniform(t);
+                    tk_seq = udiv_magic(t, P.div_bpj_m, P.div_bpj_s);
+                    tk_b = t - tk_seq * P.bpj;
+                    have_ticket = true;
+                }
+                const unsigned sl = tk_seq % RTW_NSLOT;
+                JobSlot *S = &sh->slot[sl];
+                unsigned rs = uniform(__hip_atomic_load(&S->ready_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (rs == RTW_SLOT_FREE && tk_b == 0u) {
+                    // this wave opens the job: claim the slot, take a job from the global queue, zero the accumulators
+                    unsigned won = 0;
+                    if (lane == 0) {
+                        unsigned expect = RTW_SLOT_FREE;
+                        won = __hip_atomic_compare_exchange_strong(&S->ready_seq, &expect, RTW_SLOT_OPENING, __ATOMIC_ACQUIRE,
+                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+                    }
+                    if (uniform(won)) {
+                        unsigned g, n_valid = 0;
+                        for (;;) {
+                            g = 0;
+                            if (lane == 0) g = atomicAdd(&ctr->next_job, 1u);
+                            g = uniform(g);
+                            if (g >= P.total_jobs) { g = RTW_JOB_EOF; break; }
+                            int i0, j0; unsigned k;
+                            job_pixel(P, g, lane & 15u, i0, j0, k);
+                            n_valid = (unsigned)__popcll(__ballot(lane < RTW_JOB_PX && i0 < P.height && j0 < P.width));
+                            if (n_valid) break;                        // (blocks entirely outside the image are skipped)
+                        }
+                        if (g != RTW_JOB_EOF) {
+                            if (lane < (RTW_JOB_PX * 7 * 8) / 16) reinterpret_cast<uint4 *>(&S->acc[0][0])[lane] = uint4{0u, 0u, 0u, 0u};
+                            if (lane == 0) S->remaining = (int)(n_valid * (unsigned)P.n_chunks);
+                        }
+                        if (lane == 0) S->job = g;
+                        __hip_atomic_store(&S->ready_seq, tk_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        rs = tk_seq;
+                    }
+                }
+                if (rs < RTW_SLOT_OPENING) {
+                    const unsigned job = uniform(S->job);
+                    if (job == RTW_JOB_EOF) {
+                        // the global queue is exhausted (this slot stays marked for good): these lanes are done
+                        if (need) alive = false;
+                        have_ticket = false;
+                    } else if (rs == tk_seq) {
+                        pool_slot = sl; pool_job = job; pool_b = tk_b;
+                        pool_next = 0; pool_end = 64;
+                        have_ticket = false;
+                    }
+                }
+            }
+            // hand out items of the wave's batch: item p = (pixel p & 15, chunk 4 b + (p >> 4))
+            const unsigned long long take_mask = __ballot(need && alive);
+            if (take_mask && pool_next < pool_end) {
+                const unsigned rank = (unsigned)__popcll(take_mask & ((1ull << lane) - 1ull));
+                const unsigned p = pool_next + rank;
+                if (need && alive && p < pool_end) {
+                    const unsigned px = p & 15u, chunk = pool_b * RTW_JOB_CPB + (p >> 4);
+                    int i0, j0; unsigned k;
+                    job_pixel(P, pool_job, px, i0, j0, k);
+                    if ((int)chunk < P.n_chunks && i0 < P.height && j0 < P.width) {
+                        pu = (T)((double)(j0 + 1) / (double)P.width);                 // T(j / W),       src/render.jl:26
+                        pv = (T)((double)(P.height - (i0 + 1)) / (double)P.height);   // T((H - i) / H), src/render.jl:27
+                        const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
+                        rng_stream(P.seed, pix, chunk, rng);
+                        s_global = (int)chunk * P.chunk_spp;
+                        const int s_end = min(P.spp, s_global + P.chunk_spp);
+                        samples_left = s_end - s_global;
+                        item_ref = pool_slot * 16u + px;
+                        acc_r = acc_g = acc_b = 0.0;
+                        have_item = true;
+                    }
+                    // padding item (chunk beyond n_chunks, pixel outside the image): nothing to do, pull again
+                }
+                pool_next = min(pool_end, pool_next + (unsigned)__popcll(take_mask));
+            }
+        }
+        if (!__any(alive)) break;
+        clk.lap(0);
+
+        // ---- (B) start the next sample (src/render.jl:29-37): jitter, then the lens disk in (R) ----
+        if (alive && !has_ray && todo == PATH_READY && samples_left > 0) {
+            T du = 0, dv = 0;
+            if (s_global != 0) {
+                T r1, r2;
+                trand(rng, r1); du = r1 / w_div;
+                trand(rng, r2); dv = r2 / h_div;
+            }
+            su = pu + du; sv = pv + dv;
+            new_sample = true;
+            samples_left -= 1;
+            s_global += 1;
+        }
+        n_samples += (unsigned long long)__popcll(__ballot(new_sample));
+
+        // ---- (R) ONE rejection loop for every lane that needs a random point: unit ball for
+        //      Lambertian / Metal scatter (src/rand.jl:15-22), unit disk for the lens (:31-38) ----
+        const bool ball = todo == PATH_BALL;
+        V3<T> rp = {0, 0, 0};
+        T len2 = 0;
+        {
+            bool pending = ball || new_sample;
+            while (__any(pending)) {
+                if (pending) {
+                    len2 = reject_trial<T>(rng, ball, rp);
+                    pending = !(len2 <= T(1));
+                }
+            }
+        }
+        // ---- (F) finish the scatter / the camera ray; ONE normalize for all of them ----
+        if (ball) {
+            todo = scatter_finish<T>(kind, vec, vscale_, rp, len2, vec);
+            if (todo == PATH_READY) rd = vec;                     // degenerate Lambertian direction: n, as is
+        }
+        if (new_sample) {
+            __asm__ volatile("" ::: "memory");                    // (keeps the camera loads inside this branch)
+            const Camera<T> cam = sh->cam;
+            camera_ray_raw<T>(cam, su, sv, rp.x, rp.y, ro, vec);   // src/camera.jl:43-48
+            todo = PATH_NORM;
+            thr_r = thr_g = thr_b = 1.0;
+            depth_left = P.max_depth;
+        }
+        if (todo == PATH_NORM) rd = normalize(vec);
+        if (ball || new_sample || todo == PATH_NORM) {
+            has_ray = depth_left > 0;    // depth <= 0: ray_color returns 0 (src/ray_color.jl:15)
+            todo = PATH_READY;
+            new_sample = false;
+        }
+        clk.lap(1);
+        if (!__any(has_ray)) __builtin_amdgcn_s_sleep(2);    // every lane waits for a job slot: do not hammer LDS
     }
 
     if (PROFILE && lane == 0) {
         for (int k = 0; k < 8; ++k) atomicAdd(&ctr->phase[k], clk.acc[k]);
     }
-    // counters (one atomic per lane at the very end; the compiler reduces them per wave)
-    atomicAdd(&ctr->segments, (unsigned long long)my_segments);
-    atomicAdd(&ctr->samples, (unsigned long long)my_samples);
-}
-
-// One thread per local pixel: chunk sums added in chunk order, / spp, gamma, store RGB{T}
-// (src/render.jl:40, src/vec.jl:22).  Column-major H x W, as Matrix{RGB{T}}.
-template <typename T>
-__global__ __launch_bounds__(256) void finalize_kernel(KParams P, const double *__restrict__ partial,
-                                                      T *__restrict__ out) {
-    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned n_local = (unsigned)P.n_local_tiles * 64u;
-    if (gid >= n_local) return;
-    const unsigned k = gid >> 6, pl = gid & 63u;
-    const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
-    const int ti = (int)(t % (unsigned)P.tiles_i), tj = (int)(t / (unsigned)P.tiles_i);
-    const int i0 = ti * 8 + (int)(pl & 7u), j0 = tj * 8 + (int)(pl >> 3);
-    if (i0 >= P.height || j0 >= P.width) return;
-    const double *src = partial + (size_t)gid * (size_t)P.n_chunks * 3;
-    double r = 0.0, g = 0.0, b = 0.0;
-    for (int c = 0; c < P.n_chunks; ++c) { r += src[c * 3 + 0]; g += src[c * 3 + 1]; b += src[c * 3 + 2]; }
-    const double n = (double)P.spp;
-    r = r / n; g = g / n; b = b / n;
-    if (P.gamma) { r = __builtin_sqrt(r); g = __builtin_sqrt(g); b = __builtin_sqrt(b); }
-    T *dst = out + ((size_t)j0 * (size_t)P.height + (size_t)i0) * 3;
-    dst[0] = (T)r; dst[1] = (T)g; dst[2] = (T)b;
+    if (lane == 0) {
+        atomicAdd(&ctr->segments, n_segments);
+        atomicAdd(&ctr->samples, n_samples);
+    }
 }
 
 }  // namespace rtw

@@ -9,7 +9,11 @@ namespace rtw {
 
 enum UnitOp {
     U_HIT_SPHERE = 0, U_REFLECT = 1, U_REFRACT = 2, U_REFLECTANCE = 3, U_SCATTER = 4,
-    U_GET_RAY = 5, U_SKYCOLOR = 6, U_RNG = 7, U_HIT_WORLD = 8, U_RAY_COLOR = 9, U_NUM_OPS = 10
+    U_GET_RAY = 5, U_SKYCOLOR = 6, U_RNG = 7, U_HIT_WORLD = 8, U_RAY_COLOR = 9,
+    U_HIT_WORLD_LDS = 10,    // hit_world with the scene staged in LDS (the trace kernel's instantiation)
+    U_HIT_WORLD_CULL = 11,   // hit_world_cull (RTW_FLAG_GROUP_CULL), scene staged in LDS
+    U_FX_SUM = 12,           // exact 64.64 accumulation of 8 doubles -> rounded sum, poison count
+    U_NUM_OPS = 13
 };
 
 __host__ __device__ inline int unit_in_slots(int op) {
@@ -22,8 +26,9 @@ __host__ __device__ inline int unit_in_slots(int op) {
         case U_GET_RAY: return 4;       // state[2], s, t
         case U_SKYCOLOR: return 3;      // d[3]
         case U_RNG: return 2;           // state[2]
-        case U_HIT_WORLD: return 8;     // o[3], d[3], tmin, tmax
+        case U_HIT_WORLD: case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: return 8;     // o[3], d[3], tmin, tmax
         case U_RAY_COLOR: return 9;     // state[2], o[3], d[3], depth
+        case U_FX_SUM: return 8;        // 8 binary64 values
     }
     return 0;
 }
@@ -37,8 +42,9 @@ __host__ __device__ inline int unit_out_slots(int op) {
         case U_GET_RAY: return 8;       // state[2], o[3], d[3]
         case U_SKYCOLOR: return 3;
         case U_RNG: return 6;           // state[2], 4 uniforms
-        case U_HIT_WORLD: return 9;     // idx, t, p[3], n[3], front
+        case U_HIT_WORLD: case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: return 9;     // idx, t, p[3], n[3], front
         case U_RAY_COLOR: return 6;     // state[2], colour[3], segments
+        case U_FX_SUM: return 2;        // sum, poisoned
     }
     return 0;
 }
@@ -52,14 +58,17 @@ __device__ __forceinline__ double as_f64(uint64_t u) { return __longlong_as_doub
 
 template <typename T>
 __global__ void unit_kernel(int op, int count, const double *__restrict__ in, double *__restrict__ out,
-                            DevScene<T> scene, Camera<T> cam) {
+                            DevScene<T> scene, CullScene<T> cull, Camera<T> cam) {
+    using V4 = typename Vec4<T>::type;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ unsigned short s_list[RTW_LIST_CAP * 64];    // launched with 64-thread blocks
+    extern __shared__ __attribute__((aligned(16))) unsigned char u_smem[];   // ops 10, 11: the staged scene
     unsigned short *my_list = s_list + threadIdx.x;
     const bool live = gid < count;                          // no early return: the scan is wave-cooperative
     const double *x = in + (size_t)gid * unit_in_slots(op);
     double *y = out + (size_t)gid * unit_out_slots(op);
-    if (op != U_HIT_WORLD && op != U_RAY_COLOR && !live) return;
+    const bool coop = op == U_HIT_WORLD || op == U_RAY_COLOR || op == U_HIT_WORLD_LDS || op == U_HIT_WORLD_CULL;
+    if (!coop && !live) return;
     switch (op) {
         case U_HIT_SPHERE: {
             V3<T> c = ld3<T>(x), o = ld3<T>(x + 4), d = ld3<T>(x + 7);
@@ -117,6 +126,42 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
                 make_hitrec<T>({g.x, g.y, g.z}, m0.x, o, d, t_hit, rec);
                 y[1] = (double)rec.t; st3(y + 2, rec.p); st3(y + 5, rec.n); y[8] = rec.front ? 1.0 : 0.0;
             }
+        } break;
+        case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: {
+            V4 *lds_geom = reinterpret_cast<V4 *>(u_smem);
+            unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + (op == U_HIT_WORLD_CULL ? cull_exact_count(cull) : 0));
+            if (op == U_HIT_WORLD_CULL) stage_cull_scene<T>(cull, lds_geom, lds_orig); else stage_scene<T>(scene, lds_geom);
+            __syncthreads();
+            V3<T> o = {0, 0, 0}, d = {0, 0, 1};
+            T tmn = 0, tmx = 0;
+            if (live) { o = ld3<T>(x); d = ld3<T>(x + 3); tmn = (T)x[6]; tmx = (T)x[7]; }
+            T t_hit;
+            int idx;
+            if (op == U_HIT_WORLD_CULL)
+                idx = hit_world_cull<T, 64>(cull, (const V4 *)lds_geom, (const unsigned short *)lds_orig, o, d, tmn, tmx, t_hit, my_list);
+            else
+                idx = hit_world<T, 64>(scene, (const V4 *)lds_geom, o, d, tmn, tmx, t_hit, my_list);
+            if (!live) return;
+            for (int k = 0; k < 9; ++k) y[k] = 0.0;
+            y[0] = (double)(idx >= 0 && op == U_HIT_WORLD_CULL ? (int)cull.orig[idx] : idx);   // index in the caller's list
+            if (idx >= 0) {
+                const V4 g = op == U_HIT_WORLD_CULL ? cull.exact[idx] : scene.geom[idx];
+                const V4 m0 = op == U_HIT_WORLD_CULL ? cull.mat0[idx] : scene.mat0[idx];
+                HitRec<T> rec;
+                make_hitrec<T>({g.x, g.y, g.z}, m0.x, o, d, t_hit, rec);
+                y[1] = (double)rec.t; st3(y + 2, rec.p); st3(y + 5, rec.n); y[8] = rec.front ? 1.0 : 0.0;
+            }
+        } break;
+        case U_FX_SUM: {
+            // the trace kernel's pixel accumulation: fx_from_double -> 128-bit adds -> fx_to_double
+            unsigned long long lo = 0, hi = 0, bad = 0;
+            for (int k = 0; k < 8; ++k) {
+                unsigned long long l, h;
+                if (fx_from_double(x[k], l, h)) { const unsigned long long old = lo; lo += l; hi += h + (lo < old ? 1ull : 0ull); }
+                else bad += 1;
+            }
+            y[0] = bad ? __builtin_nan("") : fx_to_double(lo, hi);
+            y[1] = (double)bad;
         } break;
         case U_RAY_COLOR: {
             // src/ray_color.jl:14-38 as the iterative front-to-back loop of the trace kernel

@@ -29,13 +29,13 @@ def test_library_exports_every_declared_symbol(rtw):
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rtw_abi_version() == 1
+    assert L.rtw_abi_version() == 2
 
 
 def test_struct_layouts_match_header(rtw):
     from rtw_amd import _capi
     assert ctypes.sizeof(_capi.CameraF32) == 22 * 4 and ctypes.sizeof(_capi.CameraF64) == 22 * 8
-    assert ctypes.sizeof(_capi.Params) == 48 and _capi.Params.seed.offset == 16
+    assert ctypes.sizeof(_capi.Params) == 64 and _capi.Params.seed.offset == 16 and _capi.Params.device_ids.offset == 56
     assert ctypes.sizeof(_capi.Stats) == 56
     assert ctypes.sizeof(_capi.SceneF32) == 80 and _capi.SceneF32.kind.offset == 40
 
