@@ -76,7 +76,7 @@ typedef struct {
     uint64_t seed;        /* render seed; the stream of (pixel, chunk) derives from it        */
     int32_t n_chunks;     /* sample chunks per pixel, each with its own RNG stream;
                              0 = default rule min(spp, 128).  Part of the image definition
-                             (the chunk sums themselves are added exactly, in any order).      */
+                             (the sample radiances themselves are added exactly, in any order). */
     int32_t shard_index;  /* this call renders the 8x8 pixel tiles t with                      */
     int32_t shard_count;  /*   t mod shard_count == shard_index; other pixels are written 0    */
     int32_t device;       /* HIP device ordinal; -1 = current device                          */

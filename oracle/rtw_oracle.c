@@ -106,16 +106,16 @@ static inline double tand_f64(double x) { return (double)tand_ld((long double)x)
 int rtwo_max_threads(void) { return omp_get_max_threads(); }
 
 /* ------------------------------------------------------------------------------------------
- * PIXEL_STREAM pixel accumulation: the chunk sums of one pixel are
- * added EXACTLY -- each binary64 chunk sum is converted to a signed 64.64 fixed-point number
+ * PIXEL_STREAM pixel accumulation: the sample radiances of one pixel
+ * are added EXACTLY -- each binary64 radiance is converted to a signed 64.64 fixed-point number
  * (every double of magnitude in [2^-11, 2^31) is represented exactly; smaller magnitudes are
  * truncated towards zero at 2^-64) and the fixed-point numbers are added as 128-bit integers.
  * The pixel sum is that integer rounded ONCE to binary64 (round to nearest, ties to even).
  * Integer addition is associative, so the result does not depend on the order in which the
- * chunks finish -- which is what lets the device add them with LDS atomics in any order.
+ * samples finish -- which is what lets the device add them with LDS atomics in any order.
  * The reference itself adds the samples sequentially in Float64 (src/render.jl:29-39); this
- * is at least as accurate (one rounding per pixel instead of one per sample after the chunk).
- * A chunk sum that is NaN, infinite or >= 2^31 in magnitude poisons the pixel (NaN output).
+ * is at least as accurate (one rounding per pixel instead of one per sample).
+ * A radiance that is NaN, infinite or >= 2^31 in magnitude poisons the pixel (NaN output).
  * ------------------------------------------------------------------------------------------ */
 typedef unsigned __int128 u128;
 typedef struct { u128 v[3]; uint32_t poison; } fxacc;

@@ -82,8 +82,9 @@ typedef struct {
     uint64_t seed;           /* PIXEL_STREAM: stream seed.  REF_SERIAL: ignored (thread index) */
     int32_t rng_mode;        /* RTW_RNG_*                                                      */
     int32_t ref_threads;     /* REF_SERIAL: Threads.nthreads() being mirrored                  */
-    int32_t n_chunks;        /* PIXEL_STREAM: sample chunks per pixel (>=1); the chunk sums are
-                                added exactly in 64.64 fixed point (rtw_oracle.c fx_add)      */
+    int32_t n_chunks;        /* PIXEL_STREAM: sample chunks per pixel (>=1), one RNG stream each; the
+                                sample radiances are added exactly in 64.64 fixed point
+                                (rtw_oracle.c fx_add), so the chunking only selects the streams */
     int32_t product_order;   /* RTW_PRODUCT_REFERENCE: att1*(att2*(...*sky)) as the recursion
                                 unwinds (src/ray_color.jl:31); RTW_PRODUCT_FORWARD:
                                 ((att1*att2)*...)*sky, what the iterative GPU loop computes   */

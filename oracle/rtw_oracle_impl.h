@@ -319,8 +319,8 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
         }
     } else {
         /* PIXEL_STREAM: one independent Xoroshiro128+ stream per (pixel, sample chunk); the
-         * chunk sums (sequential binary64 sums of the chunk's samples) are added exactly and
-         * rounded once.  This is what a parallel device can reproduce in any completion order. */
+         * radiances of ALL the pixel's samples are added exactly and the sum is rounded once.
+         * This is what a parallel device can reproduce in any completion order. */
         int nch = P->n_chunks > 0 ? P->n_chunks : 1;
         int cs = (P->spp + nch - 1) / nch;
         int nch_eff = (P->spp + cs - 1) / cs;
@@ -335,14 +335,12 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
             g_cand_disc = 0; g_cand_fwd = 0;
             for (int ch = 0; ch < nch_eff; ++ch) {
                 rng_stream(P->seed, (uint64_t)pix, (uint64_t)ch, &c.rng);
-                c3 cs_sum = {0.0, 0.0, 0.0};
                 int s1 = (ch + 1) * cs < P->spp ? (ch + 1) * cs : P->spp;
                 for (int s = ch * cs; s < s1; ++s) {
                     c3 col = FN(sample_)(&c, w, cam, P, u, v, s);
-                    cs_sum.r += col.r; cs_sum.g += col.g; cs_sum.b += col.b;
+                    /* exact (order-independent) addition of the sample radiances: rtw_oracle.c fx_add */
+                    fx_add(&fx, 0, col.r); fx_add(&fx, 1, col.g); fx_add(&fx, 2, col.b);
                 }
-                /* exact (order-independent) addition of the chunk sums: rtw_oracle.c fx_add */
-                fx_add(&fx, 0, cs_sum.r); fx_add(&fx, 1, cs_sum.g); fx_add(&fx, 2, cs_sum.b);
             }
             c3 acc = {fx_to_double(fx.v[0]), fx_to_double(fx.v[1]), fx_to_double(fx.v[2])};
             if (fx.poison) acc.r = acc.g = acc.b = NAN;

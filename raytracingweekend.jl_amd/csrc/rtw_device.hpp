@@ -287,31 +287,15 @@ __device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned l
     const bool neg = (long long)hi < 0;
     if (neg) { lo = 0ull - lo; hi = ~hi + (lo == 0ull ? 1ull : 0ull); }
     if ((lo | hi) == 0ull) return 0.0;
-    const int p = hi ? 127 - __clzll((long long)hi) : 63 - __clzll((long long)lo);   // top set bit
-    double m;
-    int sh = 0;
-    if (p <= 52) {
-        m = (double)lo;
-    } else {
-        sh = p - 52;                                       // 1 .. 75
-        unsigned long long mant, rem_hi, rem_lo, half_hi, half_lo;
-        if (sh >= 64) {
-            mant = hi >> (sh - 64);
-            rem_hi = sh == 64 ? 0ull : (hi & ((1ull << (sh - 64)) - 1ull));
-            rem_lo = lo;
-        } else {
-            mant = (hi << (64 - sh)) | (lo >> sh);
-            rem_hi = 0ull;
-            rem_lo = lo & ((1ull << sh) - 1ull);
-        }
-        if (sh - 1 >= 64) { half_hi = 1ull << (sh - 1 - 64); half_lo = 0ull; }
-        else { half_hi = 0ull; half_lo = 1ull << (sh - 1); }
-        const bool gt = rem_hi > half_hi || (rem_hi == half_hi && rem_lo > half_lo);
-        const bool eq = rem_hi == half_hi && rem_lo == half_lo;
-        if (gt || (eq && (mant & 1ull))) mant += 1ull;
-        m = (double)mant;
-    }
-    const double v = __builtin_ldexp(m, sh - 64);
+    // normalise: shift left until bit 127 is set; the top 53 bits are the significand, the rest decides the rounding
+    const int n = hi ? __clzll((long long)hi) : 64 + __clzll((long long)lo);
+    if (n >= 64) { hi = lo << (n - 64); lo = 0ull; }
+    else if (n > 0) { hi = (hi << n) | (lo >> (64 - n)); lo <<= n; }
+    unsigned long long mant = hi >> 11;
+    const unsigned rem = (unsigned)hi & 0x7ffu;
+    const bool sticky = lo != 0ull;
+    if (rem > 0x400u || (rem == 0x400u && (sticky || (mant & 1ull)))) mant += 1ull;
+    const double v = __builtin_ldexp((double)mant, 11 - n);      // value = mant * 2^(127 - n - 52) / 2^64
     return neg ? -v : v;
 }
 

@@ -58,8 +58,12 @@ struct JobSlot {
     unsigned long long acc[RTW_JOB_PX][7];   // r.lo r.hi g.lo g.hi b.lo b.hi poison
     unsigned ready_seq;                      // RTW_SLOT_FREE | RTW_SLOT_OPENING | the job sequence number it holds
     unsigned job;                            // global job id, or RTW_JOB_EOF (queue exhausted; never freed)
-    int remaining;                           // items of the job not yet added
+    int remaining;                           // items of the job not yet finished
+    unsigned valid;                          // bit px: pixel px of the block lies inside the image
+    int i_base, j_base;                      // 0-based row / column of the block's first pixel
+    unsigned k_tile;                         // local tile index (compact output layout)
     unsigned pad;
+    double uv[8];                            // j / W for the 4 columns, (H - i) / H for the 4 rows (src/render.jl:26-27), as binary64
 };
 template <typename T> struct WgShared {
     JobSlot slot[RTW_NSLOT];
@@ -87,16 +91,6 @@ __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned 
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ unsigned uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
-// (i0, j0) of pixel `px` (0..15) of job `job`: job = 4 * (local tile) + quadrant
-__device__ __forceinline__ void job_pixel(const KParams &P, unsigned job, unsigned px, int &i0, int &j0, unsigned &k) {
-    k = job >> 2;
-    const unsigned q = job & 3u;
-    const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
-    const unsigned tj = udiv_magic(t, P.div_tiles_m, P.div_tiles_s), ti = t - tj * (unsigned)P.tiles_i;
-    i0 = (int)(ti * 8u + (q & 1u) * 4u + (px & 3u));
-    j0 = (int)(tj * 8u + (q >> 1) * 4u + (px >> 2));
-}
-
 // waves per SIMD the trace kernel is compiled for (second __launch_bounds__ argument):
 // Float32 -> 7 (VGPR cap 72), Float64 -> 4 (cap 128; the double state does not fit lower caps)
 #ifndef RTW_TRACE_WAVES_F32
@@ -115,23 +109,73 @@ template <typename T, bool CULL> struct TraceWavesOf { static constexpr int valu
 template <> struct TraceWavesOf<float, true> { static constexpr int value = RTW_TRACE_WAVES_CULL_F32; };
 template <> struct TraceWavesOf<double, true> { static constexpr int value = 3; };
 
+// Exact accumulation of one sample's radiance into pixel `a` of a job slot.
+__device__ __forceinline__ void fx_accumulate(unsigned long long *a, double r, double g, double b) {
+    const double cs[3] = {r, g, b};
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {        // not unrolled: one channel's temporaries at a time
+
+        unsigned long long lo, hi;
+        if (fx_from_double(cs[c], lo, hi)) {
+            const unsigned long long old = __hip_atomic_fetch_add(&a[2 * c], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            hi += (old + lo < old) ? 1ull : 0ull;
+            if (hi) __hip_atomic_fetch_add(&a[2 * c + 1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            __hip_atomic_fetch_add(&a[6], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
 // The store of one finished job (src/render.jl:40, src/vec.jl:22): lane = (pixel, channel).
+// (noinline on purpose, like open_job: both run once per job; as real calls their register needs and the
+// spills around them stay on that rare path instead of raising the pressure of the whole lane loop)
 template <typename T>
-__device__ __forceinline__ void store_job(const KParams &P, const JobSlot *S, unsigned job, unsigned lane, T *__restrict__ out) {
+__device__ __attribute__((noinline)) void store_job(const KParams &P, const JobSlot *S, unsigned lane, T *__restrict__ out) {
     if (lane < 3u * RTW_JOB_PX) {
         const unsigned px = lane & (RTW_JOB_PX - 1u), ch = lane >> 4;
-        int i0, j0; unsigned k;
-        job_pixel(P, job, px, i0, j0, k);
-        if (i0 < P.height && j0 < P.width) {
+        if ((S->valid >> px) & 1u) {
+            const int i0 = S->i_base + (int)(px & 3u), j0 = S->j_base + (int)(px >> 2);
             double v = fx_to_double(S->acc[px][2 * ch], S->acc[px][2 * ch + 1]);
             if (S->acc[px][6] != 0ull) v = __builtin_nan("");
             v = v / (double)P.spp;
             if (P.gamma) v = __builtin_sqrt(v);
             const size_t pix = P.out_layout == 0 ? (size_t)j0 * (size_t)P.height + (size_t)i0
-                                                 : (size_t)k * 64u + (size_t)((i0 & 7) + 8 * (j0 & 7));
+                                                 : (size_t)S->k_tile * 64u + (size_t)((i0 & 7) + 8 * (j0 & 7));
             out[pix * 3 + ch] = (T)v;
         }
     }
+}
+
+// Open a job slot (whole wave): take job ids from the global queue until one has a pixel inside the
+// image (or the queue is exhausted), zero its accumulators and fill in the block's header.
+__device__ __attribute__((noinline)) void open_job(const KParams &P, JobSlot *S, unsigned lane, DevCounters *ctr) {
+    unsigned g, valid = 0, k = 0;
+    int i_base = 0, j_base = 0;
+    for (;;) {
+        g = 0;
+        if (lane == 0) g = atomicAdd(&ctr->next_job, 1u);
+        g = uniform(g);
+        if (g >= P.total_jobs) { g = RTW_JOB_EOF; break; }
+        k = g >> 2;                                          // job = 4 * (local tile) + quadrant
+        const unsigned q = g & 3u;
+        const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
+        const unsigned tj = udiv_magic(t, P.div_tiles_m, P.div_tiles_s), ti = t - tj * (unsigned)P.tiles_i;
+        i_base = (int)(ti * 8u + (q & 1u) * 4u);
+        j_base = (int)(tj * 8u + (q >> 1) * 4u);
+        const int i0 = i_base + (int)(lane & 3u), j0 = j_base + (int)((lane >> 2) & 3u);
+        valid = (unsigned)__ballot(lane < RTW_JOB_PX && i0 < P.height && j0 < P.width);
+        if (valid) break;                                    // (blocks entirely outside the image are skipped)
+    }
+    if (g != RTW_JOB_EOF) {
+        if (lane < (RTW_JOB_PX * 7 * 8) / 16) reinterpret_cast<uint4 *>(&S->acc[0][0])[lane] = uint4{0u, 0u, 0u, 0u};
+        if (lane < 4) S->uv[lane] = (double)(j_base + (int)lane + 1) / (double)P.width;                        // j / W
+        else if (lane < 8) S->uv[lane] = (double)(P.height - (i_base + (int)lane - 4 + 1)) / (double)P.height;   // (H - i) / H
+        if (lane == 0) {
+            S->remaining = (int)((unsigned)__popc(valid) * (unsigned)P.n_chunks);
+            S->valid = valid; S->i_base = i_base; S->j_base = j_base; S->k_tile = k;
+        }
+    }
+    if (lane == 0) S->job = g;
 }
 
 template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL>
@@ -157,28 +201,21 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
 
     // ---- wave-uniform state ----
     unsigned pool_next = 0, pool_end = 0;   // unassigned items [pool_next, pool_end) of the wave's current batch
-    unsigned pool_slot = 0, pool_job = 0, pool_b = 0;
+    unsigned pool_slot = 0, pool_b = 0;
     bool have_ticket = false;               // a batch ticket drawn but not yet usable (its job slot is not open)
     unsigned tk_seq = 0, tk_b = 0;
     unsigned long long n_segments = 0, n_samples = 0;
 
-    // ---- per-lane state ----
+    // ---- per-lane state that lives across iterations (and so across the scan) ----
     bool alive = true;        // still pulling work
-    bool have_item = false;   // owns an item whose chunk sum is not yet added
+    bool have_item = false;   // owns an item (its job's `remaining` is decremented when the chunk is done)
     bool has_ray = false;     // a ray is ready for the scan
-    int todo = PATH_READY;    // PATH_BALL: scatter waits for a unit-ball sample; PATH_NORM: direction to normalise
-    bool new_sample = false;  // camera ray under construction (waits for a unit-disk sample)
     unsigned item_ref = 0;    // slot * 16 + pixel of the owned item
     int samples_left = 0;
-    int s_global = 0;         // 0-based sample index within the pixel (sample 0 is un-jittered)
-    T pu = 0, pv = 0;         // pixel's (u, v)  (src/render.jl:26-27), then (u + du, v + dv) of the sample
+    bool jitter = false;      // false only for sample 1 of the pixel (src/render.jl:30-31)
+    T pu = 0, pv = 0;         // pixel's (u, v)  (src/render.jl:26-27)
     Rng rng = {1, 2};
-    double acc_r = 0, acc_g = 0, acc_b = 0;
     V3<T> ro = {0, 0, 0}, rd = {0, 0, 1};
-    V3<T> vec = {0, 0, 0};    // PATH_BALL: n (Lambertian) / reflect(d, n) (Metal); PATH_NORM: the raw direction
-    T vscale_ = 1;            // PATH_BALL: 1 (Lambertian) / fuzz (Metal)
-    int kind = 0;
-    T su = 0, sv = 0;
     double thr_r = 1, thr_g = 1, thr_b = 1;
     int depth_left = 0;
 
@@ -205,62 +242,31 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
         n_segments += (unsigned long long)__popcll(__ballot(has_ray));
         clk.lap(2);
 
-        // ---- (H) shade (src/ray_color.jl:20-37): sky ends the sample; a hit starts the scatter ----
-        if (has_ray) {
-            has_ray = false;
-            if (idx < 0) {
-                const C3 sky = skycolor(rd);
-                acc_r += thr_r * sky.r; acc_g += thr_g * sky.g; acc_b += thr_b * sky.b;
-            } else {
-                const V4 g = CULL ? cull.exact[idx] : scene.geom[idx];    // CULL: device order
-                const V4 m0 = CULL ? cull.mat0[idx] : scene.mat0[idx];
-                const V4 m1 = CULL ? cull.mat1[idx] : scene.mat1[idx];
-                HitRec<T> rec;
-                make_hitrec<T>({g.x, g.y, g.z}, m0.x, ro, rd, t_hit, rec);
-                kind = (int)m0.z;
-                todo = scatter_begin<T>(rng, kind, m0.y, rd, rec, vec, vscale_);
-                const V3<T> att = attenuation_of<T>(kind, {m1.x, m1.y, m1.z});
-                thr_r = thr_r * (double)att.x; thr_g = thr_g * (double)att.y; thr_b = thr_b * (double)att.z;
-                ro = rec.p;
-                depth_left -= 1;
-                if (todo == PATH_READY) { rd = vec; has_ray = depth_left > 0; }   // depth 0: ray_color returns 0
-            }
+        // ---- (H1) a miss ends the sample: its radiance thr * sky (src/ray_color.jl:36) is added EXACTLY
+        //      to the pixel's accumulators in LDS (a path that runs out of depth adds 0: nothing to do) ----
+        const bool hit = has_ray && idx >= 0;
+        if (has_ray && idx < 0) {
+            const C3 sky = skycolor(rd);
+            fx_accumulate(sh->slot[item_ref >> 4].acc[item_ref & 15u], thr_r * sky.r, thr_g * sky.g, thr_b * sky.b);
         }
-        clk.lap(3);
+        has_ray = false;
 
-        // ---- (A) lanes whose chunk is done add it to their job, retire jobs, take the next item ----
-        const bool idle = alive && !has_ray && todo == PATH_READY;           // no path in flight
-        const bool need = idle && samples_left == 0;
+        // ---- (A) lanes whose chunk is done retire it, finished jobs are stored, new items are taken ----
+        const bool need = alive && !hit && samples_left == 0;
         const unsigned long long need_mask = __ballot(need);
         if (need_mask) {
             bool last = false;
             if (need && have_item) {
-                JobSlot *S = &sh->slot[item_ref >> 4];
-                unsigned long long *a = S->acc[item_ref & 15u];
-                const double cs[3] = {acc_r, acc_g, acc_b};
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    unsigned long long lo, hi;
-                    if (fx_from_double(cs[c], lo, hi)) {
-                        const unsigned long long old = __hip_atomic_fetch_add(&a[2 * c], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        hi += (old + lo < old) ? 1ull : 0ull;
-                        if (hi) __hip_atomic_fetch_add(&a[2 * c + 1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    } else {
-                        __hip_atomic_fetch_add(&a[6], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-                last = __hip_atomic_fetch_add(&S->remaining, -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
+                last = __hip_atomic_fetch_add(&sh->slot[item_ref >> 4].remaining, -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
                 have_item = false;
             }
-            // jobs whose last item was just added: the wave stores their 16 pixels and frees the slot
+            // jobs whose last item just finished: the wave stores their 16 pixels and frees the slot
             unsigned long long fin = __ballot(last);
             while (fin) {
                 const int L = __builtin_ctzll(fin);
                 fin &= fin - 1ull;
-                const unsigned sl = uniform((unsigned)__shfl((int)(item_ref >> 4), L));
-                JobSlot *S = &sh->slot[sl];
-                const unsigned job = uniform(S->job);
-                store_job<T>(P, S, job, lane, out);
+                JobSlot *S = &sh->slot[uniform((unsigned)__shfl((int)(item_ref >> 4), L))];
+                store_job<T>(P, S, lane, out);
                 __hip_atomic_store(&S->ready_seq, RTW_SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // a wave without unassigned items draws a batch ticket and tries to make it usable
@@ -285,34 +291,18 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
                     }
                     if (uniform(won)) {
-                        unsigned g, n_valid = 0;
-                        for (;;) {
-                            g = 0;
-                            if (lane == 0) g = atomicAdd(&ctr->next_job, 1u);
-                            g = uniform(g);
-                            if (g >= P.total_jobs) { g = RTW_JOB_EOF; break; }
-                            int i0, j0; unsigned k;
-                            job_pixel(P, g, lane & 15u, i0, j0, k);
-                            n_valid = (unsigned)__popcll(__ballot(lane < RTW_JOB_PX && i0 < P.height && j0 < P.width));
-                            if (n_valid) break;                        // (blocks entirely outside the image are skipped)
-                        }
-                        if (g != RTW_JOB_EOF) {
-                            if (lane < (RTW_JOB_PX * 7 * 8) / 16) reinterpret_cast<uint4 *>(&S->acc[0][0])[lane] = uint4{0u, 0u, 0u, 0u};
-                            if (lane == 0) S->remaining = (int)(n_valid * (unsigned)P.n_chunks);
-                        }
-                        if (lane == 0) S->job = g;
+                        open_job(P, S, lane, ctr);
                         __hip_atomic_store(&S->ready_seq, tk_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         rs = tk_seq;
                     }
                 }
                 if (rs < RTW_SLOT_OPENING) {
-                    const unsigned job = uniform(S->job);
-                    if (job == RTW_JOB_EOF) {
+                    if (uniform(S->job) == RTW_JOB_EOF) {
                         // the global queue is exhausted (this slot stays marked for good): these lanes are done
                         if (need) alive = false;
                         have_ticket = false;
                     } else if (rs == tk_seq) {
-                        pool_slot = sl; pool_job = job; pool_b = tk_b;
+                        pool_slot = sl; pool_b = tk_b;
                         pool_next = 0; pool_end = 64;
                         have_ticket = false;
                     }
@@ -324,19 +314,18 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
                 const unsigned rank = (unsigned)__popcll(take_mask & ((1ull << lane) - 1ull));
                 const unsigned p = pool_next + rank;
                 if (need && alive && p < pool_end) {
+                    const JobSlot *S = &sh->slot[pool_slot];
                     const unsigned px = p & 15u, chunk = pool_b * RTW_JOB_CPB + (p >> 4);
-                    int i0, j0; unsigned k;
-                    job_pixel(P, pool_job, px, i0, j0, k);
-                    if ((int)chunk < P.n_chunks && i0 < P.height && j0 < P.width) {
-                        pu = (T)((double)(j0 + 1) / (double)P.width);                 // T(j / W),       src/render.jl:26
-                        pv = (T)((double)(P.height - (i0 + 1)) / (double)P.height);   // T((H - i) / H), src/render.jl:27
+                    if ((int)chunk < P.n_chunks && ((S->valid >> px) & 1u)) {
+                        const int i0 = S->i_base + (int)(px & 3u), j0 = S->j_base + (int)(px >> 2);
+                        pu = (T)S->uv[px >> 2];                                       // T(j / W),       src/render.jl:26
+                        pv = (T)S->uv[4 + (px & 3u)];                                 // T((H - i) / H), src/render.jl:27
                         const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
                         rng_stream(P.seed, pix, chunk, rng);
-                        s_global = (int)chunk * P.chunk_spp;
-                        const int s_end = min(P.spp, s_global + P.chunk_spp);
-                        samples_left = s_end - s_global;
+                        const int s0 = (int)chunk * P.chunk_spp;
+                        samples_left = min(P.spp, s0 + P.chunk_spp) - s0;
+                        jitter = s0 != 0;                                             // sample 1 of the pixel is centred
                         item_ref = pool_slot * 16u + px;
-                        acc_r = acc_g = acc_b = 0.0;
                         have_item = true;
                     }
                     // padding item (chunk beyond n_chunks, pixel outside the image): nothing to do, pull again
@@ -347,18 +336,41 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
         if (!__any(alive)) break;
         clk.lap(0);
 
+        // ---- (H2) a hit starts the scatter (src/ray_color.jl:20-33) ----
+        int todo = PATH_READY;    // PATH_BALL: scatter waits for a unit-ball sample; PATH_NORM: direction to normalise
+        V3<T> vec = {0, 0, 0};    // PATH_BALL: n (Lambertian) / reflect(d, n) (Metal); PATH_NORM: the raw direction
+        T vscale_ = 1;            // PATH_BALL: 1 (Lambertian) / fuzz (Metal)
+        int kind = 0;
+        if (hit) {
+            const V4 g = CULL ? cull.exact[idx] : scene.geom[idx];    // CULL: device order
+            const V4 m0 = CULL ? cull.mat0[idx] : scene.mat0[idx];
+            const V4 m1 = CULL ? cull.mat1[idx] : scene.mat1[idx];
+            HitRec<T> rec;
+            make_hitrec<T>({g.x, g.y, g.z}, m0.x, ro, rd, t_hit, rec);
+            kind = (int)m0.z;
+            todo = scatter_begin<T>(rng, kind, m0.y, rd, rec, vec, vscale_);
+            const V3<T> att = attenuation_of<T>(kind, {m1.x, m1.y, m1.z});
+            thr_r = thr_r * (double)att.x; thr_g = thr_g * (double)att.y; thr_b = thr_b * (double)att.z;
+            ro = rec.p;
+            depth_left -= 1;
+            if (todo == PATH_READY) { rd = vec; has_ray = depth_left > 0; }   // depth 0: ray_color returns 0
+        }
+        clk.lap(3);
+
         // ---- (B) start the next sample (src/render.jl:29-37): jitter, then the lens disk in (R) ----
-        if (alive && !has_ray && todo == PATH_READY && samples_left > 0) {
+        bool new_sample = false;  // camera ray under construction (waits for a unit-disk sample)
+        T su = 0, sv = 0;         // (u + du, v + dv)
+        if (alive && !hit && samples_left > 0) {
             T du = 0, dv = 0;
-            if (s_global != 0) {
+            if (jitter) {
                 T r1, r2;
                 trand(rng, r1); du = r1 / w_div;
                 trand(rng, r2); dv = r2 / h_div;
             }
             su = pu + du; sv = pv + dv;
             new_sample = true;
+            jitter = true;
             samples_left -= 1;
-            s_global += 1;
         }
         n_samples += (unsigned long long)__popcll(__ballot(new_sample));
 
@@ -390,11 +402,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
             depth_left = P.max_depth;
         }
         if (todo == PATH_NORM) rd = normalize(vec);
-        if (ball || new_sample || todo == PATH_NORM) {
-            has_ray = depth_left > 0;    // depth <= 0: ray_color returns 0 (src/ray_color.jl:15)
-            todo = PATH_READY;
-            new_sample = false;
-        }
+        if (ball || new_sample || todo == PATH_NORM) has_ray = depth_left > 0;   // depth <= 0: ray_color returns 0 (src/ray_color.jl:15)
         clk.lap(1);
         if (!__any(has_ray)) __builtin_amdgcn_s_sleep(2);    // every lane waits for a job slot: do not hammer LDS
     }
