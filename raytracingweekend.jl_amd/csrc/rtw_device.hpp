@@ -303,7 +303,7 @@ __device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned l
 // geom[i] = (cx, cy, cz, r*r)   hot: 16 B (f32) / 32 B (f64) per sphere, wave-uniform reads
 // mat0[i] = (r, param, kind, 0) cold: read once per segment by the lane that hit sphere i
 // mat1[i] = (ar, ag, ab, 0)
-// geom is padded to a multiple of 2*G spheres (one software-pipeline pair) plus one prefetch group
+// geom is padded to a multiple of G spheres (one scalar-load group) plus one prefetch group
 // with spheres that can never be hit (r*r = -1e30 => discriminant < 0 always).
 #define RTW_SPHERE_WORD 32
 #define RTW_SPHERE_TAIL 8
@@ -311,7 +311,7 @@ template <typename T> struct DevScene {
     const typename Vec4<T>::type *geom;
     const typename Vec4<T>::type *mat0;
     const typename Vec4<T>::type *mat1;
-    int n, n_pad;   // n_pad: multiple of 2*ScanGroup<T>::N (the tail group lies beyond n_pad)
+    int n, n_pad;   // n_pad: multiple of ScanGroup<T>::N (the tail group lies beyond n_pad)
 };
 
 // Candidate lists: pass 1 of the scan appends the indices of the spheres whose discriminant is
@@ -382,9 +382,10 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
     };
     for (int base = 0; base < w.n_pad; base += RTW_SPHERE_WORD) {
         uint32_t mask = 0;
-        // the last word may be partial: n_pad is a multiple of one pair of groups (2G), not of 32
+        // the last word may be partial: n_pad is a multiple of one group (G), not of 32
         const int left = w.n_pad - base;
-        const int npairs = left >= RTW_SPHERE_WORD ? RTW_SPHERE_WORD / (2 * G) : left / (2 * G);
+        const int ngroups = (left >= RTW_SPHERE_WORD ? RTW_SPHERE_WORD : left) / G;
+        const int npairs = ngroups >> 1;
         for (int q = 0; q < npairs; ++q) {
             const int off = base + q * 2 * G;
             // Scalar loads return out of order, so every wait is lgkmcnt(0).  To keep a group's
@@ -407,21 +408,30 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
             for (int k = 1; k < G; ++k) test1(B[k], mask);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (ngroups & 1) {                        // odd group count: the scene's last group, already in A
+#pragma unroll
+            for (int k = 0; k < G; ++k) test1(A[k], mask);
+        }
         clk.lap(2);
         uint32_t m = ~mask;                       // bit 31 = sphere `base`, bit 0 = sphere base+31
-        if (left < RTW_SPHERE_WORD) m <<= (RTW_SPHERE_WORD - npairs * 2 * G);   // partial word: align to bit 31
-        while (__any(m != 0u)) {
-            if (__any(cnt >= RTW_LIST_CAP)) {     // some lane's list is full: resolve all lists now
-                clk.lap(4);
-                resolve_candidates<T, STRIDE>(src, o, d, tmin, closest, idx, list, cnt);
-                cnt = 0;
-                clk.lap(5);
-            }
-            if (m != 0u) {
-                const int b = __clz((int)m);
-                list[cnt * STRIDE] = (unsigned short)(base + b);
-                cnt += 1;
-                m &= ~(0x80000000u >> b);
+        if (left < RTW_SPHERE_WORD) m <<= (RTW_SPHERE_WORD - ngroups * G);   // partial word: align to bit 31
+        auto push_first = [&]() {                 // append the lane's first remaining candidate of this word
+            const int b = __clz((int)m);
+            list[cnt * STRIDE] = (unsigned short)(base + b);
+            cnt += 1;
+            m &= ~(0x80000000u >> b);
+        };
+        if (!__any(cnt + (int)__popc(m) > RTW_LIST_CAP)) {
+            while (__any(m != 0u)) { if (m != 0u) push_first(); }          // the common case: a tight loop
+        } else {
+            while (__any(m != 0u)) {
+                if (__any(cnt >= RTW_LIST_CAP)) {     // some lane's list is full: resolve all lists now
+                    clk.lap(4);
+                    resolve_candidates<T, STRIDE>(src, o, d, tmin, closest, idx, list, cnt);
+                    cnt = 0;
+                    clk.lap(5);
+                }
+                if (m != 0u) push_first();
             }
         }
         clk.lap(4);

@@ -303,8 +303,8 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     HIP_TRY(hipSetDevice(dev));
     using V4 = typename rtw::Vec4<T>::type;
     const int n = s->n;
-    constexpr int pair = 2 * rtw::ScanGroup<T>::N;                                       // 16 (f32) / 8 (f64)
-    const int n_pad = ((n + pair - 1) / pair) * pair;                                    // 0 spheres: no scan at all
+    constexpr int grp = rtw::ScanGroup<T>::N;                                            // 8 (f32) / 4 (f64)
+    const int n_pad = ((n + grp - 1) / grp) * grp;                                       // 0 spheres: no scan at all
     const int n_alloc = n_pad + RTW_SPHERE_TAIL;                                          // prefetch tail group
     if (n_pad >= 65536) return fail(-5, "too many spheres (%d): candidate lists hold 16-bit indices", n);
     std::vector<V4> geom(n_alloc), mat0(n_alloc), mat1(n_alloc);
