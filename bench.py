@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the hot path render -> ray_color -> hit/scatter on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--dtype f32|f64] [--width 1920|3840]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one full render of BASELINE.json's headline workload (configs[2]):
+One "step" = one full render of the workload.  Default = BASELINE.json's headline, configs[2]:
 scene_random_spheres (reseed!(); 485 spheres), camera t_cam1, 1920x1080, 1000 spp, depth 50,
-Float32, scene already resident in HBM, image left in HBM on rank 0.  With N > 1 ranks the SAME
-image is tile-sharded over the ranks (strong scaling) and the zero-padded shard framebuffers are
-summed onto rank 0 with one RCCL reduce over xGMI inside the timed region.
+Float32.  `--dtype f64 --width 3840` is the single-GPU share of configs[4] (3840x2160, Float64).
+The scene is already resident in HBM when the timed region starts and the image is left in HBM
+on rank 0.  With N > 1 ranks the SAME image is tile-sharded over the ranks (strong scaling) and
+the zero-padded shard framebuffers are summed onto rank 0 with one RCCL reduce over xGMI inside
+the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- FP32 VALU roofline of the dominant kernel (trace_kernel): algorithmic flops =
-                  counted ray-sphere tests x 17 flop (/root/reference/src/hit.jl:13-19),
-                  divided by the kernel's HIP-event time on its launch stream; plus the HBM figure
-                  the north star asks for (algorithmic bytes / time vs 8 TB/s).
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     -- VALU roofline of the only kernel (rtw::trace_kernel): algorithmic flops =
+                  counted ray-sphere tests x 17 flop (/root/reference/src/hit.jl:13-19)
+                  divided by the kernel's HIP-event time on its launch stream, against the FP32
+                  (157.3 TF) or FP64 (78.6 TF) vector peak; `traffic` = HBM bytes per launch from
+                  the committed PMC passes (profiles/), plus the algorithmic HBM figure vs 8 TB/s.
   cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
-                  bounded sample of the same workload (same image, fewer spp).
+                  bounded sample of the same workload (same image, fewer spp); `cpu_baseline_16t`
+                  is the same with 16 threads (the north star's comparison point).
+  accelerated  -- the opt-in RTW_FLAG_GROUP_CULL mode (same image bit for bit), reported separately.
+  end_to_end   -- one call of the host-buffer entry point rtw_render_* (scene upload, render,
+                  D2H of the image: the PCIe-inclusive rate; never `value`).
+  depth16      -- the same workload at the reference's own depth (src/ray_color.jl:14).
 """
 import argparse
 import json
@@ -29,7 +37,9 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-FP32_VALU_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix)
+# /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 vector 157.3 TFLOP/s (= 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz);
+# the guide lists no FP64 vector figure: AMD's MI355X datasheet gives 78.6 TFLOP/s (half the FP32 rate).
+VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
 HBM_PEAK_GBS = 8000.0
 FLOP_PER_TEST = 17              # 3 sub + 5 + 5 (dots) + mul/sub + mul/sub, src/hit.jl:13-19
 
@@ -39,15 +49,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the accelerated / end_to_end / depth16 legs")
     ap.add_argument("--group-cull", action="store_true", help="time the opt-in accelerated scan instead of the plain one")
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per pixel (0 = library default rule)")
     ap.add_argument("--emulate-shard-of", type=int, default=0,
                     help="analysis only: on ONE GPU render shard 0 of N (what each rank of an N-GPU run does)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration per leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,7 +81,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
-    T = np.float32
+    T = np.float64 if args.dtype == "f64" else np.float32
+    tT = torch.float64 if args.dtype == "f64" else torch.float32
+    jl = "Float64" if args.dtype == "f64" else "Float32"
     W, spp, depth = args.width, args.spp, args.depth
     H = R.image_height(W)
     R.reseed()                                              # src/proto/proto.jl:198-199
@@ -77,136 +91,155 @@ def main():
     cam = R.t_cam1(elem_type=T)
     n_spheres = len(scene)
     renderer = R.DeviceRenderer(scene, cam, device=local_rank)
-    fb = torch.empty(H * W * 3, dtype=torch.float32, device=dev)
+    fb = torch.empty(H * W * 3, dtype=tT, device=dev)
     stream = torch.cuda.current_stream(dev)
-
-    kernel_ms, total_ms, tests, segments = [], [], [], []
-    stats_chunks = [0]
-
-    def step(record):
-        def shard(idx, cnt):
-            if args.emulate_shard_of > 1:
-                idx, cnt = 0, args.emulate_shard_of
-            renderer.render_into(fb.data_ptr(), W, spp, depth=depth, seed=1, n_chunks=args.chunks, shard_index=idx,
-                                 shard_count=cnt, stream=stream.cuda_stream, group_cull=args.group_cull)
-            return fb
-        R.render_sharded(shard, W)                          # renders this rank's tiles, one reduce onto rank 0
-        if record:
-            st = renderer.stats()                           # waits for this rank's kernels (HIP events on `stream`)
-            kernel_ms.append(st["kernel_ms"]); total_ms.append(st["total_ms"]); stats_chunks[0] = st["n_chunks"]
-            tests.append(st["sphere_tests"]); segments.append(st["segments"])
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        agg = torch.tensor([sum(tests), sum(segments), max(kernel_ms) if kernel_ms else 0.0], dtype=torch.float64, device=dev)
-        tot = agg.clone(); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        kmax = agg[2:3].clone(); dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-        all_tests, all_segments = float(tot[0]), float(tot[1])
-    else:
-        all_tests, all_segments = float(sum(tests)), float(sum(segments))
+    def timed(n_steps, n_warm, *, cull, depth_, record=None):
+        """W untimed + K timed steps bracketed by barrier + synchronize; returns max-over-ranks seconds."""
+        def step(rec):
+            def shard(idx, cnt):
+                if args.emulate_shard_of > 1:
+                    idx, cnt = 0, args.emulate_shard_of
+                renderer.render_into(fb.data_ptr(), W, spp, depth=depth_, seed=1, n_chunks=args.chunks, shard_index=idx,
+                                     shard_count=cnt, stream=stream.cuda_stream, group_cull=cull)
+                return fb
+            R.render_sharded(shard, W)                      # renders this rank's tiles, one reduce onto rank 0
+            if rec is not None:
+                rec.append(renderer.stats())                # waits for this rank's kernel (HIP events on `stream`)
+        for _ in range(n_warm):
+            step(None)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(record)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
 
-    samples_per_step = W * H * spp
+    stats = []
+    dt = timed(args.steps, args.warmup, cull=args.group_cull, depth_=depth, record=stats)
+    kernel_ms = [s["kernel_ms"] for s in stats]
+    tests = [s["sphere_tests"] for s in stats]
+    segments = [s["segments"] for s in stats]
+    if world > 1:
+        agg = torch.tensor([sum(tests), sum(segments)], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        all_segments = float(agg[1])
+    else:
+        all_segments = float(sum(segments))
+
+    shard_div = args.emulate_shard_of if args.emulate_shard_of > 1 else 1
+    samples_per_step = W * H * spp / shard_div
     value = samples_per_step * args.steps / dt / 1e6
 
-    # the opt-in accelerated scan (RTW_FLAG_GROUP_CULL, bit-identical image), timed the same way, reported
-    # separately: `value` stays the reference's plain linear scan so that the roofline figure means what it says
-    accel = None
-    if not args.group_cull and args.emulate_shard_of <= 1:
-        def step_accel():
-            def shard(idx, cnt):
-                renderer.render_into(fb.data_ptr(), W, spp, depth=depth, seed=1, n_chunks=args.chunks, shard_index=idx,
-                                     shard_count=cnt, stream=stream.cuda_stream, group_cull=True)
-                return fb
-            R.render_sharded(shard, W)
-        step_accel()
-        fence()
-        ta = time.perf_counter()
-        for _ in range(args.steps):
-            step_accel()
-        fence()
-        dta = time.perf_counter() - ta
-        if world > 1:
-            tmax = torch.tensor([dta], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dta = float(tmax.item())
+    extras = not args.no_extras and args.emulate_shard_of <= 1
+    accel = depth16 = None
+    if extras and not args.group_cull:
+        # the opt-in accelerated scan (RTW_FLAG_GROUP_CULL, bit-identical image), timed the same way, reported
+        # separately: `value` stays the reference's plain linear scan so that the roofline figure means what it says
+        dta = timed(args.steps, 1, cull=True, depth_=depth)
         accel = {"mode": "RTW_FLAG_GROUP_CULL (kd clusters of 16 + conservative per-ray grown AABB slab test; same image bit for bit)",
                  "value": round(samples_per_step * args.steps / dta / 1e6, 2), "unit": "Msamples/s",
                  "ms_per_step": round(dta / args.steps * 1e3, 3)}
+    if extras and depth != 16:
+        st16 = []
+        dt16 = timed(1, 0, cull=args.group_cull, depth_=16, record=st16)
+        depth16 = {"value": round(samples_per_step / dt16 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt16 * 1e3, 3),
+                   "segments_per_sample": round(st16[0]["segments"] * world / samples_per_step, 4) if world == 1 else None,
+                   "note": "same workload at depth 16, the reference's only depth (src/ray_color.jl:14)"}
+
+    end_to_end = None
+    if extras and world == 1 and rank == 0:
+        # host-buffer entry point, what the Julia ccall binds: scene upload + render + image D2H, blocking
+        t = time.perf_counter()
+        R.render(scene, cam, W, spp, depth=depth, seed=1, n_chunks=args.chunks, device=local_rank, group_cull=args.group_cull)
+        te = time.perf_counter() - t
+        end_to_end = {"value": round(W * H * spp / te / 1e6, 2), "unit": "Msamples/s", "ms": round(te * 1e3, 3),
+                      "kernel_ms": round(R.last_stats()["kernel_ms"], 3),
+                      "note": "rtw_render_* on host buffers: H2D scene, render, D2H image (PCIe-inclusive); never `value`"}
 
     if rank == 0:
-        # dominant kernel = trace_kernel.  Per launch (this rank's shard): algorithmic flops =
+        # the only kernel = trace_kernel.  Per launch (this rank's shard): algorithmic flops =
         # sphere tests x 17; duration = mean HIP-event time on the launch stream.
         k_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
         tests_per_launch = sum(tests) / len(tests)
+        peak = VALU_PEAK_TFLOPS[args.dtype]
         achieved_tflops = tests_per_launch * FLOP_PER_TEST / k_s / 1e12
-        alg_bytes = W * H * 3 * 4 / world + n_spheres * 48        # framebuffer write + one scene read
-        # HBM bytes per launch from the committed PMC passes (profiles/), valid for the default workload only
-        traffic = None
+        esize = 8 if args.dtype == "f64" else 4
+        alg_bytes = W * H * 3 * esize / world / shard_div + n_spheres * 12 * esize   # framebuffer write + one scene read
+        # HBM bytes per launch from the committed PMC passes (profiles/), valid for the exact workload they were taken on
+        traffic = traffic_src = None
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_1080p_1000spp.json")))
-            if (W, spp, depth, world) == (1920, 1000, 50, 1):
-                traffic = tr["hbm_bytes_per_launch"]
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
+            key = f"{args.dtype}_{W}x{H}_{spp}spp_d{depth}_{'cull' if args.group_cull else 'plain'}"
+            if world == 1 and shard_div == 1 and key in tr:
+                traffic, traffic_src = tr[key]["hbm_bytes_per_launch"], tr[key].get("source")
         except Exception:
             pass
         roofline = {
-            "bound": "valu_fp32", "kernel": "rtw::trace_kernel<float>",
-            "achieved": round(achieved_tflops, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved_tflops / FP32_VALU_PEAK_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+            "bound": "valu_" + ("fp64" if args.dtype == "f64" else "fp32"), "kernel": f"rtw::trace_kernel<{'double' if args.dtype == 'f64' else 'float'}>",
+            "achieved": round(achieved_tflops, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved_tflops / peak, 4),
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+            "traffic_source": traffic_src,
             "kernel_ms": round(k_s * 1e3, 3), "tests_per_launch": int(tests_per_launch),
-            "flop_per_test": FLOP_PER_TEST, "segments_per_sample": round(all_segments / (samples_per_step * args.steps), 4),
-            "note": "peak = MI355X FP32 vector peak (= dense FP32 MFMA peak); the path has no dense contraction, so no MFMA",
+            "flop_per_test": FLOP_PER_TEST, "segments_per_sample": round(all_segments / (samples_per_step * shard_div * args.steps), 4),
+            "note": "peak = MI355X vector peak of the arithmetic type (FP32 157.3 TF from MI355X_MICROARCH.md; FP64 78.6 TF from the "
+                    "datasheet); the path has no dense contraction, so no MFMA.  The bare 11-instruction test loop tops out at "
+                    "0.58 of the FP32 peak on this chip (tools/ubench_issue.hip: 2.6 cycles per VALU instruction at 7-8 waves/SIMD)",
             "hbm": {"algorithmic_bytes": int(alg_bytes), "achieved_GBs": round(alg_bytes / k_s / 1e9, 4),
                     "peak_GBs": HBM_PEAK_GBS, "frac": round(alg_bytes / k_s / 1e9 / HBM_PEAK_GBS, 8)},
         }
-        cpu = None
+        cpu = cpu16 = None
         if world == 1 and not args.no_cpu_baseline:
             import rtw_oracle as O
             O.build()
             flat = R.flatten_scene(scene, T)
             threads = O.max_threads()
-            t = time.perf_counter()
-            O.render(flat, cam, W, H, 1, T=T, max_depth=depth, seed=1, n_chunks=1)
-            t1 = time.perf_counter() - t
-            s_spp = int(max(1, min(64, round(args.cpu_seconds / max(t1, 1e-3)))))
-            t = time.perf_counter()
-            O.render(flat, cam, W, H, s_spp, T=T, max_depth=depth, seed=1)
-            tc = time.perf_counter() - t
-            cpu = {"value": round(W * H * s_spp / tc / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-                   "sample": f"same scene/camera/{W}x{H}/depth {depth}, {s_spp} spp ({tc:.1f} s), oracle/ C port with OpenMP; "
-                             f"the Julia reference cannot run here (no julia in the image)"}
-        if args.emulate_shard_of > 1:
-            samples_per_step = samples_per_step / args.emulate_shard_of
-            value = samples_per_step * args.steps / dt / 1e6
+
+            def cpu_leg(nthr):
+                t = time.perf_counter()
+                O.render(flat, cam, W, H, 1, T=T, max_depth=depth, seed=1, n_chunks=1, omp_threads=nthr)
+                t1 = time.perf_counter() - t
+                s_spp = int(max(1, min(64, round(args.cpu_seconds / max(t1, 1e-3)))))
+                t = time.perf_counter()
+                O.render(flat, cam, W, H, s_spp, T=T, max_depth=depth, seed=1, omp_threads=nthr)
+                tc = time.perf_counter() - t
+                return {"value": round(W * H * s_spp / tc / 1e6, 4), "unit": "Msamples/s", "cores": nthr, "kind": "port",
+                        "sample": f"same scene/camera/{W}x{H}/depth {depth}/{jl}, {s_spp} spp ({tc:.1f} s), oracle/ C port with OpenMP; "
+                                  f"the Julia reference cannot run here (no julia in the image)"}
+            cpu = cpu_leg(threads)
+            if threads > 16:
+                cpu16 = cpu_leg(16)
+        cfg_name = {("f32", 1920, 1000, 50): "BASELINE.json configs[2]" if world == 1 else "BASELINE.json configs[3]",
+                    ("f64", 3840, 1000, 50): "BASELINE.json configs[4]" + (", one GPU" if world == 1 else "")}.get(
+            (args.dtype, W, spp, depth), "not a BASELINE config")
         line = {
-            "metric": "Msamples/s (pixels x spp) on scene_random_spheres 1920x1080",
+            "metric": f"Msamples/s (pixels x spp) on scene_random_spheres {W}x{H}",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"scene_random_spheres ({n_spheres} spheres, reseed!() seed 1), t_cam1, {W}x{H}, {spp} spp, "
-                                   f"depth {depth}, Float32 (BASELINE.json configs[2])",
+                                   f"depth {depth}, {jl} ({cfg_name})",
                        "scan": "group_cull (opt-in)" if args.group_cull else "plain linear scan over all spheres (reference algorithm)",
                        "parallelism": f"tile-sharded x{world}" + (" + 1 RCCL reduce" if world > 1 else ""),
-                       "rng": f"Xoroshiro128+ per (pixel, chunk), {stats_chunks[0]} chunks/pixel"},
-            "roofline": roofline, "cpu_baseline": cpu, "accelerated": accel,
+                       "rng": f"Xoroshiro128+ per (pixel, chunk), {stats[0]['n_chunks']} chunks/pixel; exact fixed-point pixel accumulation"},
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_16t": cpu16, "accelerated": accel,
+            "end_to_end": end_to_end, "depth16": depth16,
         }
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        if cpu16:
+            line["gpu_over_cpu_16t"] = round(value / cpu16["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

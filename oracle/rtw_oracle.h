@@ -132,6 +132,11 @@ int rtwo_hit_sphere_f32(const float c[3], float r, const float o[3], const float
 int rtwo_hit_sphere_f64(const double c[3], double r, const double o[3], const double d[3],
                         double tmin, double tmax, double rec[8]);
 /* hit(::HittableList): returns index of the closest sphere or -1 */
+/* n rays at once (rays = n x {o[3], d[3]}): idx[i] = -1 on a miss, t[i] = the hit distance */
+void rtwo_hit_world_batch_f32(const rtwo_scene_f32 *, const float *rays, long n, float tmin, float tmax,
+                              int32_t *idx, float *t);
+void rtwo_hit_world_batch_f64(const rtwo_scene_f64 *, const double *rays, long n, double tmin, double tmax,
+                              int32_t *idx, double *t);
 int rtwo_hit_world_f32(const rtwo_scene_f32 *, const float o[3], const float d[3],
                        float tmin, float tmax, float rec[8]);
 int rtwo_hit_world_f64(const rtwo_scene_f64 *, const double o[3], const double d[3],

@@ -230,6 +230,22 @@ def hit_world(flat_scene, o, d, tmin, tmax, T=np.float64):
     return idx, rec
 
 
+def hit_world_batch(flat_scene, rays, tmin, tmax, T=np.float64):
+    """rays: [n, 6] (o, d) -> (idx[n] int32, t[n] of dtype T), all rays in one C call (OpenMP)"""
+    S, keep = make_scene(flat_scene, T)
+    rays = np.ascontiguousarray(rays, dtype=T)
+    n = rays.shape[0]
+    idx = np.zeros(n, np.int32)
+    t = np.zeros(n, T)
+    fn = getattr(lib(), "rtwo_hit_world_batch_f64" if _is64(T) else "rtwo_hit_world_batch_f32")
+    ct = _ct(T)
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_long, ct, ct, C.c_void_p, C.c_void_p]
+    fn(C.byref(S), _p(rays), n, float(tmin), float(tmax), _p(idx), _p(t))
+    del keep
+    return idx, t
+
+
 def scatter(kind, albedo, param, d, rec8, state, T=np.float64):
     """-> (out9 = o,d,att ; new state)"""
     st = np.array(state, dtype=np.uint64)

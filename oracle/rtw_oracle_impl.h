@@ -453,6 +453,16 @@ int FN(rtwo_hit_world_)(const SCENE_T *w, const T o[3], const T d[3], T tmin, T 
     if (idx >= 0) FN(rec_out_)(&h, rec);
     return idx;
 }
+/* batched closest hit for the randomized scan stress tests: rays = n x (o[3], d[3]); idx[i] = -1 on a miss */
+void FN(rtwo_hit_world_batch_)(const SCENE_T *w, const T *rays, long n, T tmin, T tmax, int32_t *idx, T *t) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        HREC h;
+        h.t = (T)0;
+        idx[i] = FN(hit_world_)(w, FN(ld3_)(rays + 6 * i), FN(ld3_)(rays + 6 * i + 3), tmin, tmax, &h);
+        t[i] = idx[i] >= 0 ? h.t : (T)0;
+    }
+}
 int FN(rtwo_scatter_)(int kind, const T albedo[3], T param, const T d[3], const T rec[8],
                       uint64_t state[2], T out[9]) {
     octx c; c.draws = 0; c.segments = 0; c.rng.x = state[0]; c.rng.y = state[1];

@@ -63,4 +63,6 @@ GOLDEN_CASES = [
     "random_64x36_8spp_d50_f64",
     "diel_bubble_96x54_8spp_d16_f32",
     "metal4_96x54_8spp_d16_f32",
+    "diel_plus_96x54_8spp_d16_f32",
+    "blue_red_96x54_8spp_d16_f64",
 ]

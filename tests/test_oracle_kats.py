@@ -137,3 +137,27 @@ def test_height_rule(rtw):
     # src/render.jl:11-12  image_width ÷ 16//9   
     for w, h in [(96, 54), (200, 112), (320, 180), (400, 225), (1920, 1080), (3840, 2160)]:
         assert rtw.image_height(w) == h
+
+
+def test_exact_fixed_point_accumulation_vs_rational_arithmetic(oracle):
+    """PIXEL_STREAM pixel accumulation (oracle/rtw_oracle.c fx_add / fx_to_double): the 64.64
+    fixed-point sum rounded once equals the exactly computed rational sum (each term truncated
+    towards zero at 2^-64) rounded to nearest-even, for any order of the terms."""
+    from fractions import Fraction
+    rng = np.random.default_rng(1)
+    for trial in range(300):
+        n = int(rng.integers(1, 200))
+        x = rng.uniform(0, 8, n) * rng.choice([1, 1, 1, 1e-3, 1e-9, -1, 2.0 ** -30, 1e5], n)
+        s, bad = oracle.fx_sum(x)
+        tot = Fraction(0)
+        for v in x:
+            q = abs(Fraction(float(v))) * 2 ** 64
+            tot += Fraction(q.numerator // q.denominator, 2 ** 64) * (1 if v >= 0 else -1)
+        assert bad == 0 and s == float(tot), (trial, s, float(tot))          # Fraction -> float rounds correctly
+        assert oracle.fx_sum(x[::-1].copy())[0] == s and oracle.fx_sum(rng.permutation(x))[0] == s
+    assert oracle.fx_sum([0.1] * 10) == (1.0, 0)                                # sequential binary64 adds give 0.9999999999999999
+    assert oracle.fx_sum([2.0 ** 31 - 1, 0.5]) == (2147483647.5, 0)
+    assert oracle.fx_sum([1.0, 2.0 ** -53]) == (1.0, 0) and oracle.fx_sum([1.0, 2.0 ** -53, 2.0 ** -60])[0] == 1.0 + 2.0 ** -52
+    for poison in (float("nan"), float("inf"), -float("inf"), 2.0 ** 31, -2.0 ** 40):
+        s, bad = oracle.fx_sum([1.0, poison])
+        assert bad == 1 and np.isnan(s)

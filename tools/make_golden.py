@@ -67,6 +67,12 @@ def main():
          R.t_cam2(elem_type=f32), 96, 8, 16, f32)
     case("metal4_96x54_8spp_d16_f32", R.flatten_scene(R.scene_4_spheres(elem_type=f32), f32),
          R.t_default_cam(elem_type=f32), 96, 8, 16, f32)
+    # the remaining reference scenes (src/scenes.jl:25-47; src/proto/proto.jl:94,104,271): both hollow-glass
+    # signs and the Float64-only blue/red scene (R = cos(pi/4) is a Float64 literal there)
+    case("diel_plus_96x54_8spp_d16_f32", R.flatten_scene(R.scene_diel_spheres(0.5, elem_type=f32), f32),
+         R.t_cam2(elem_type=f32), 96, 8, 16, f32)
+    case("blue_red_96x54_8spp_d16_f64", R.flatten_scene(R.scene_blue_red_spheres(elem_type=f64), f64),
+         R.t_default_cam(elem_type=f64), 96, 8, 16, f64)
     # provisional RNG / scene vectors (unpinned against Julia: DESIGN.md section 3)
     st = O.rng_seed(1)
     u64 = [O.rng_next(st) for _ in range(16)]
