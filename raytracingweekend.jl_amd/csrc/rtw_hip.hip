@@ -349,7 +349,7 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (!p) return fail(-1, "null params");
     if (p->width <= 0 || p->height <= 0) return fail(-2, "width/height must be positive (got %d x %d)", p->width, p->height);
     if (p->spp <= 0) return fail(-2, "spp must be positive (got %d)", p->spp);
-    if (p->max_depth < 0) return fail(-2, "max_depth must be >= 0");
+    if (p->max_depth < 0 || p->max_depth >= (1 << 24)) return fail(-2, "max_depth must be in [0, 2^24)");
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");

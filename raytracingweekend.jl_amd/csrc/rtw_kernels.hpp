@@ -70,6 +70,7 @@ template <typename T> struct WgShared {
     unsigned ticket;                         // next batch of this workgroup
     unsigned pad[3];
     Camera<T> cam;                           // read per new sample (keeps 22 SGPRs out of the scan loop)
+    KParams P;                               // read where needed (item pull, store): not held in SGPRs across the scan
 };
 
 // Phase profiler (opt-in instantiation, never used for timed runs): s_memtime stamps around
@@ -92,12 +93,12 @@ __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ unsigned uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
 // waves per SIMD the trace kernel is compiled for (second __launch_bounds__ argument):
-// Float32 -> 7 (VGPR cap 72), Float64 -> 4 (cap 128; the double state does not fit lower caps)
+// Float32 -> 7 (VGPR cap 72), Float64 -> 5 (cap 96; measured 1.5 % faster than 4 waves at 126 VGPRs)
 #ifndef RTW_TRACE_WAVES_F32
 #define RTW_TRACE_WAVES_F32 7
 #endif
 #ifndef RTW_TRACE_WAVES_F64
-#define RTW_TRACE_WAVES_F64 4
+#define RTW_TRACE_WAVES_F64 5
 #endif
 template <typename T> struct TraceWaves { static constexpr int value = RTW_TRACE_WAVES_F32; };
 template <> struct TraceWaves<double> { static constexpr int value = RTW_TRACE_WAVES_F64; };
@@ -108,6 +109,12 @@ template <> struct TraceWaves<double> { static constexpr int value = RTW_TRACE_W
 template <typename T, bool CULL> struct TraceWavesOf { static constexpr int value = TraceWaves<T>::value; };
 template <> struct TraceWavesOf<float, true> { static constexpr int value = RTW_TRACE_WAVES_CULL_F32; };
 template <> struct TraceWavesOf<double, true> { static constexpr int value = 3; };
+
+// store_job / open_job run once per job.  Inlined: as real calls (noinline) they keep the lane loop's register
+// pressure lower, but every call saves ~20 live VGPRs to scratch -- 2.7 GB of HBM writes per frame (PMC).
+#ifndef RTW_RARE_ATTR
+#define RTW_RARE_ATTR __forceinline__
+#endif
 
 // Exact accumulation of one sample's radiance into pixel `a` of a job slot.
 __device__ __forceinline__ void fx_accumulate(unsigned long long *a, double r, double g, double b) {
@@ -127,10 +134,8 @@ __device__ __forceinline__ void fx_accumulate(unsigned long long *a, double r, d
 }
 
 // The store of one finished job (src/render.jl:40, src/vec.jl:22): lane = (pixel, channel).
-// (noinline on purpose, like open_job: both run once per job; as real calls their register needs and the
-// spills around them stay on that rare path instead of raising the pressure of the whole lane loop)
 template <typename T>
-__device__ __attribute__((noinline)) void store_job(const KParams &P, const JobSlot *S, unsigned lane, T *__restrict__ out) {
+__device__ RTW_RARE_ATTR void store_job(const KParams &P, const JobSlot *S, unsigned lane, T *__restrict__ out) {
     if (lane < 3u * RTW_JOB_PX) {
         const unsigned px = lane & (RTW_JOB_PX - 1u), ch = lane >> 4;
         if ((S->valid >> px) & 1u) {
@@ -148,7 +153,7 @@ __device__ __attribute__((noinline)) void store_job(const KParams &P, const JobS
 
 // Open a job slot (whole wave): take job ids from the global queue until one has a pixel inside the
 // image (or the queue is exhausted), zero its accumulators and fill in the block's header.
-__device__ __attribute__((noinline)) void open_job(const KParams &P, JobSlot *S, unsigned lane, DevCounters *ctr) {
+__device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned lane, DevCounters *ctr) {
     unsigned g, valid = 0, k = 0;
     int i_base = 0, j_base = 0;
     for (;;) {
@@ -179,7 +184,7 @@ __device__ __attribute__((noinline)) void open_job(const KParams &P, JobSlot *S,
 }
 
 template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL>
-__global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_kernel(KParams P, Camera<T> cam_arg, DevScene<T> scene,
+__global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_kernel(KParams P_arg, Camera<T> cam_arg, DevScene<T> scene,
                                                    CullScene<T> cull, T *__restrict__ out, DevCounters *ctr) {
     using V4 = typename Vec4<T>::type;
     const unsigned lane = lane_id();
@@ -192,7 +197,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
     V4 *lds_geom = reinterpret_cast<V4 *>(smem + list_bytes + shared_bytes);
     unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + (CULL ? cull_exact_count(cull) : 0));
     if (threadIdx.x < RTW_NSLOT) { sh->slot[threadIdx.x].ready_seq = RTW_SLOT_FREE; sh->slot[threadIdx.x].job = 0u; }
-    if (threadIdx.x == 0) { sh->ticket = 0u; sh->cam = cam_arg; }
+    if (threadIdx.x == 0) { sh->ticket = 0u; sh->cam = cam_arg; sh->P = P_arg; }
+    const KParams &P = sh->P;
     if (LDS_SCENE) {
         if (CULL) stage_cull_scene<T>(cull, lds_geom, lds_orig);
         else stage_scene<T>(scene, lds_geom);
@@ -210,14 +216,12 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
     bool alive = true;        // still pulling work
     bool have_item = false;   // owns an item (its job's `remaining` is decremented when the chunk is done)
     bool has_ray = false;     // a ray is ready for the scan
-    unsigned item_ref = 0;    // slot * 16 + pixel of the owned item
+    unsigned ref_depth = 0;   // (bounces left << 7) | item_ref, item_ref = slot * 16 + pixel of the owned item
     int samples_left = 0;
     bool jitter = false;      // false only for sample 1 of the pixel (src/render.jl:30-31)
-    T pu = 0, pv = 0;         // pixel's (u, v)  (src/render.jl:26-27)
     Rng rng = {1, 2};
     V3<T> ro = {0, 0, 0}, rd = {0, 0, 1};
     double thr_r = 1, thr_g = 1, thr_b = 1;
-    int depth_left = 0;
 
     const T w_div = (T)(float)P.width;    // f32_image_width  (src/render.jl:16)
     const T h_div = (T)(float)P.height;   // f32_image_height (src/render.jl:17)
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
         const bool hit = has_ray && idx >= 0;
         if (has_ray && idx < 0) {
             const C3 sky = skycolor(rd);
+            const unsigned item_ref = ref_depth & 127u;
             fx_accumulate(sh->slot[item_ref >> 4].acc[item_ref & 15u], thr_r * sky.r, thr_g * sky.g, thr_b * sky.b);
         }
         has_ray = false;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
         if (need_mask) {
             bool last = false;
             if (need && have_item) {
-                last = __hip_atomic_fetch_add(&sh->slot[item_ref >> 4].remaining, -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
+                last = __hip_atomic_fetch_add(&sh->slot[(ref_depth & 127u) >> 4].remaining, -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
                 have_item = false;
             }
             // jobs whose last item just finished: the wave stores their 16 pixels and frees the slot
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
             while (fin) {
                 const int L = __builtin_ctzll(fin);
                 fin &= fin - 1ull;
-                JobSlot *S = &sh->slot[uniform((unsigned)__shfl((int)(item_ref >> 4), L))];
+                JobSlot *S = &sh->slot[uniform((unsigned)__shfl((int)((ref_depth & 127u) >> 4), L))];
                 store_job<T>(P, S, lane, out);
                 __hip_atomic_store(&S->ready_seq, RTW_SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -318,14 +323,12 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
                     const unsigned px = p & 15u, chunk = pool_b * RTW_JOB_CPB + (p >> 4);
                     if ((int)chunk < P.n_chunks && ((S->valid >> px) & 1u)) {
                         const int i0 = S->i_base + (int)(px & 3u), j0 = S->j_base + (int)(px >> 2);
-                        pu = (T)S->uv[px >> 2];                                       // T(j / W),       src/render.jl:26
-                        pv = (T)S->uv[4 + (px & 3u)];                                 // T((H - i) / H), src/render.jl:27
                         const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
                         rng_stream(P.seed, pix, chunk, rng);
                         const int s0 = (int)chunk * P.chunk_spp;
                         samples_left = min(P.spp, s0 + P.chunk_spp) - s0;
                         jitter = s0 != 0;                                             // sample 1 of the pixel is centred
-                        item_ref = pool_slot * 16u + px;
+                        ref_depth = pool_slot * 16u + px;
                         have_item = true;
                     }
                     // padding item (chunk beyond n_chunks, pixel outside the image): nothing to do, pull again
@@ -352,8 +355,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
             const V3<T> att = attenuation_of<T>(kind, {m1.x, m1.y, m1.z});
             thr_r = thr_r * (double)att.x; thr_g = thr_g * (double)att.y; thr_b = thr_b * (double)att.z;
             ro = rec.p;
-            depth_left -= 1;
-            if (todo == PATH_READY) { rd = vec; has_ray = depth_left > 0; }   // depth 0: ray_color returns 0
+            ref_depth -= 128u;                                                  // one bounce used
+            if (todo == PATH_READY) { rd = vec; has_ray = ref_depth >= 128u; }   // depth 0: ray_color returns 0
         }
         clk.lap(3);
 
@@ -367,7 +370,10 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
                 trand(rng, r1); du = r1 / w_div;
                 trand(rng, r2); dv = r2 / h_div;
             }
-            su = pu + du; sv = pv + dv;
+            const JobSlot *S = &sh->slot[(ref_depth & 127u) >> 4];
+            const unsigned px = ref_depth & 15u;
+            su = (T)S->uv[px >> 2] + du;                  // T(j / W) + du,       src/render.jl:26,37
+            sv = (T)S->uv[4 + (px & 3u)] + dv;            // T((H - i) / H) + dv, src/render.jl:27,37
             new_sample = true;
             jitter = true;
             samples_left -= 1;
@@ -399,10 +405,10 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
             camera_ray_raw<T>(cam, su, sv, rp.x, rp.y, ro, vec);   // src/camera.jl:43-48
             todo = PATH_NORM;
             thr_r = thr_g = thr_b = 1.0;
-            depth_left = P.max_depth;
+            ref_depth = (ref_depth & 127u) | ((unsigned)P.max_depth << 7);
         }
         if (todo == PATH_NORM) rd = normalize(vec);
-        if (ball || new_sample || todo == PATH_NORM) has_ray = depth_left > 0;   // depth <= 0: ray_color returns 0 (src/ray_color.jl:15)
+        if (ball || new_sample || todo == PATH_NORM) has_ray = ref_depth >= 128u;   // depth <= 0: ray_color returns 0 (src/ray_color.jl:15)
         clk.lap(1);
         if (!__any(has_ray)) __builtin_amdgcn_s_sleep(2);    // every lane waits for a job slot: do not hammer LDS
     }
