@@ -459,6 +459,8 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 //     relative errors of a few u to parameters of size <= |o - Cs| + Rs, far below m/2
 //     (9 sqrt(u) = 2.2e-3 < kappa/2 = 1.95e-3 ... kappa covers both with the +1 term); direction
 //     components smaller than 1e-9 are replaced by +-1e-9 (moves the ray by < 1e-9 t).
+//     All of this assumes a unit direction; hit_world_cull widens m by 2 sqrt(|d|^2 - 1) for the rays that
+//     are not (found by comparing both modes at 1080p x 1000 spp: 8 pixels differed in round 1).
 //   * level 2 (per lane): the members of every touched cluster are tested with the contract
 //     discriminant (sphere data gathered from LDS) and the candidates in front of the ray are
 //     pushed to the lane's list.
@@ -544,9 +546,19 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
         member(V4{gx[4 * i], gx[4 * i + 1], gx[4 * i + 2], gx[4 * i + 3]}, i);
     }
 
-    // per-ray constants of the slab test
+    // per-ray constants of the slab test.  The margin argument above is geometric and needs |d| = 1, but the
+    // reference does NOT renormalise a dielectric reflection (src/material.jl:48): along chains of internal
+    // reflections s2 = |d|^2 drifts (1 + 1e-3 ... 400 occur about once per 10^9 segments of the headline scene;
+    // round 1's cull lost 8 pixels of the 1080p x 1000 spp frame to it).  With eps = s2 - 1 > 0 the contract
+    // discriminant accepts spheres within  r + sqrt(eps) |L| + 4.5 sqrt(u) |d| (|o - c| + r)  of the LINE
+    // (L = (o - c).d / |d|, |L| <= |o - c|), so the margin grows with the ray's own eps:
+    //     m = (kappa * max(1, s2) + 2 sqrt(eps+)) * (|o - Cs| + Rs + 1),   eps+ = max(s2 - 1, 0) + 4u s2
+    // (kappa / 2 >= 4.5 sqrt(u) as before; the 4u s2 covers the rounding of s2 itself).  eps < 0 only shrinks
+    // the accepted set.  A wildly non-unit ray simply touches every cluster.
     const V3<T> ocs = {o.x - w.cs[0], o.y - w.cs[1], o.z - w.cs[2]};
-    const T margin = w.kappa * ((t_sqrt(dot(ocs, ocs)) + w.rs) + T(1));
+    const T s2 = dot(d, d);
+    const T eps_p = (s2 > T(1) ? s2 - T(1) : T(0)) + (sizeof(T) == 4 ? T(2.4e-7) : T(4.5e-16)) * s2;
+    const T margin = (w.kappa * (s2 > T(1) ? s2 : T(1)) + T(2) * t_sqrt(eps_p)) * ((t_sqrt(dot(ocs, ocs)) + w.rs) + T(1));
     auto safe_inv = [](T x) { const T e = T(1e-9); const T y = (x < e && x > -e) ? (x < T(0) ? -e : e) : x; return T(1) / y; };
     const V3<T> inv = {safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
     const V3<T> op = {o.x + margin, o.y + margin, o.z + margin};     // lo' - o = lo - (o + m)

@@ -246,6 +246,10 @@ def _stress_rays(rng, flat, m, T, scale):
     nrm = np.sqrt((d.astype(T) ** 2).sum(1, dtype=T)).astype(T)
     nrm[nrm == 0] = 1
     d = (d / nrm[:, None]).astype(T)
+    # the reference does not renormalise dielectric reflections (src/material.jl:48): directions drift away from
+    # unit length along internal-reflection chains; the scans must agree with the oracle for those rays as well
+    off = rng.random(m) < 0.15
+    d[off] = (d[off] * rng.choice([1 + 3e-7, 1 - 3e-7, 1 + 2e-6, 1.0009, 0.97, 1.0097, 1.08, 3.0, 20.8], (int(off.sum()), 1))).astype(T)
     return np.concatenate([o, d], 1)
 
 
@@ -271,6 +275,26 @@ def test_scan_stress_plain_lds_and_cull_agree_with_oracle(oracle, T):
         total += m
         assert n == 0 or (ref_idx >= 0).mean() > 0.02
     assert total > 1_000_000
+
+
+def test_group_cull_identical_at_headline_scale(rtw):
+    """BASELINE configs[2] in full (1920x1080, 1000 spp, depth 50: 8.2e9 ray segments): the opt-in
+    group-cull mode must give the plain scan's image bit for bit and the same segment count.  (Round 1's
+    cull differed in 8 pixels here: rays with a non-unit direction, about one per 10^9 segments.)"""
+    import torch
+    T = np.float32
+    rtw.reseed()
+    dr = rtw.DeviceRenderer(rtw.scene_random_spheres(elem_type=T), rtw.t_cam1(elem_type=T), device=0)
+    a = torch.empty(1080 * 1920 * 3, dtype=torch.float32, device="cuda:0")
+    b = torch.empty_like(a)
+    s = torch.cuda.current_stream()
+    dr.render_into(a.data_ptr(), 1920, 1000, depth=50, seed=1, stream=s.cuda_stream)
+    sa = dr.stats()
+    dr.render_into(b.data_ptr(), 1920, 1000, depth=50, seed=1, stream=s.cuda_stream, group_cull=True)
+    sb = dr.stats()
+    assert sa["segments"] == sb["segments"] and sa["samples"] == 1920 * 1080 * 1000
+    assert bool(torch.equal(a, b)), int((a != b).sum())
+    dr.close()
 
 
 # ---- tier T3: statistical parity with the reference's own sampling order ---------------------------
