@@ -472,6 +472,9 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 #define RTW_CULL_GS 16   // spheres per cluster (multiple of 8)
 #endif
 #define RTW_CULL_BG 4    // cluster boxes per SGPR set: 4 x 8 floats = 2 x s_load_dwordx16
+#ifndef RTW_CULL_L2
+#define RTW_CULL_L2 4    // cluster members gathered from LDS per step of level 2 (8 costs 16 more VGPRs: spills)
+#endif
 template <typename T> struct CullScene {
     const T *box;                          // 8 T per cluster: lo.xyz, pad, hi.xyz, pad; padded + tail group
     const typename Vec4<T>::type *exact;   // (cx, cy, cz, r*r), cluster-major then big class
@@ -612,12 +615,12 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
                 m &= ~(0x80000000u >> b);
                 const int first = (base + b) * GS;
 #pragma unroll 1
-                for (int h = 0; h < GS; h += 8) {
-                    V4 sp[8];
+                for (int h = 0; h < GS; h += RTW_CULL_L2) {
+                    V4 sp[RTW_CULL_L2];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) sp[j] = src[first + h + j];
+                    for (int j = 0; j < RTW_CULL_L2; ++j) sp[j] = src[first + h + j];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) member(sp[j], first + h + j);
+                    for (int j = 0; j < RTW_CULL_L2; ++j) member(sp[j], first + h + j);
                 }
             }
         }
