@@ -75,7 +75,7 @@ typedef struct {
     int32_t max_depth;    /* ray_color depth; reference default 16 (src/ray_color.jl:14)      */
     uint64_t seed;        /* render seed; the stream of (pixel, chunk) derives from it        */
     int32_t n_chunks;     /* sample chunks per pixel, each with its own RNG stream;
-                             0 = default rule min(spp, 128).  Part of the image definition
+                             0 = default rule min(spp, clamp(spp / 4, 16, 256)).  Part of the image definition
                              (the sample radiances themselves are added exactly, in any order). */
     int32_t shard_index;  /* this call renders the 8x8 pixel tiles t with                      */
     int32_t shard_count;  /*   t mod shard_count == shard_index; other pixels are written 0    */
@@ -86,7 +86,8 @@ typedef struct {
                              named by `device`; N > 1 = the N ordinals in device_ids; -1 = every visible
                              device.  The 8x8 tiles are dealt round-robin to the devices (one host thread,
                              stream and PCIe link each); the image is identical for every device list.   */
-    int32_t reserved;     /* 0 */
+    int32_t job_pixels;   /* 0 = automatic.  1, 4 or 16: pixels per work-queue job (1x1, 2x2, 4x4 block).
+                             Scheduling granularity only -- the image is identical for every value.      */
     const int32_t *device_ids; /* n_devices > 1: HIP ordinals; an ordinal may repeat (its shards then run
                              concurrently on that device)                                               */
 } rtw_params;

@@ -37,7 +37,7 @@ class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("seed", C.c_uint64), ("n_chunks", C.c_int32), ("shard_index", C.c_int32),
                 ("shard_count", C.c_int32), ("device", C.c_int32), ("gamma", C.c_int32), ("flags", C.c_int32),
-                ("n_devices", C.c_int32), ("reserved", C.c_int32), ("device_ids", C.POINTER(C.c_int32))]
+                ("n_devices", C.c_int32), ("job_pixels", C.c_int32), ("device_ids", C.POINTER(C.c_int32))]
 
 
 class Stats(C.Structure):
@@ -123,11 +123,11 @@ ABI_VERSION = 2
 
 
 def make_params(width, height, spp, max_depth=16, seed=1, n_chunks=0, shard_index=0, shard_count=1,
-                device=-1, gamma=1, flags=0, devices=None):
+                device=-1, gamma=1, flags=0, devices=None, job_pixels=0):
     """``devices``: None / int ordinal -> one device; "all" -> every visible device (n_devices = -1);
     a sequence of ordinals -> that device list (host-buffer entry points only)."""
     P = Params(int(width), int(height), int(spp), int(max_depth), int(seed), int(n_chunks),
-               int(shard_index), int(shard_count), int(device), int(gamma), int(flags), 0, 0, None)
+               int(shard_index), int(shard_count), int(device), int(gamma), int(flags), 0, int(job_pixels), None)
     if devices is None:
         return P
     if isinstance(devices, str):

@@ -354,7 +354,9 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
     if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES)) return fail(-2, "unknown flags 0x%x", p->flags);
-    int nch = p->n_chunks > 0 ? p->n_chunks : (p->spp < 128 ? p->spp : 128);
+    // default rule: about 4 samples per chunk, between 16 and 256 chunks (never more than spp):
+    // enough items for load balance, few enough stream set-ups (1 sample per chunk costs 7 % at Float64)
+    int nch = p->n_chunks > 0 ? p->n_chunks : std::min(p->spp, std::max(16, std::min(256, p->spp / 4)));
     if (nch > p->spp) nch = p->spp;
     int cs = (p->spp + nch - 1) / nch;
     *chunk_spp = cs;
@@ -387,13 +389,8 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     K.shard_index = p->shard_index; K.shard_count = p->shard_count;
     K.tiles_i = (p->height + 7) / 8; K.tiles_j = (p->width + 7) / 8;
     const long long n_local = local_tiles(p);
-    const long long total_jobs = n_local * 4;
-    const long long bpj = (nch + RTW_JOB_CPB - 1) / RTW_JOB_CPB;
-    if (total_jobs >= (1ll << 31) || total_jobs * bpj >= (1ll << 40))
-        return fail(-5, "render too large for one call: %lld pixel-block jobs", total_jobs);
-    K.total_jobs = (unsigned)total_jobs; K.bpj = (unsigned)bpj; K.gamma = p->gamma;
+    K.gamma = p->gamma;
     K.out_layout = (p->flags & RTW_FLAG_COMPACT_TILES) ? 1 : 0;
-    make_udiv((unsigned)bpj, &K.div_bpj_m, &K.div_bpj_s);
     make_udiv((unsigned)K.tiles_i, &K.div_tiles_m, &K.div_tiles_s);
 
     rtw::Camera<T> C;
@@ -429,6 +426,23 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 256, lds_bytes));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     long long grid = (long long)ctx->num_cus * blocks_per_cu;
+    // Job size: 2x2 pixels (a batch = 4 pixels x 16 chunks) unless there are too few chunks to fill such a
+    // batch, then 4x4 (16 pixels x 4 chunks).  Measured at 1080p x 1000 spp (tools/gpu_drain.py): the end-of-queue
+    // drain is 10 ms with 2x2 jobs and 33 ms with 4x4 jobs (full frame 871 vs 885 ms; a 1/8 shard 120 vs 140 ms);
+    // one-pixel jobs starve the 6 job slots of a workgroup (full frame 1160 ms).
+    int job_shift = nch >= 16 ? 2 : 4;
+    if (p->job_pixels == 16 || p->job_pixels == 4 || p->job_pixels == 1) {
+        job_shift = p->job_pixels == 16 ? 4 : p->job_pixels == 4 ? 2 : 0;
+    } else if (p->job_pixels != 0) {
+        return fail(-2, "job_pixels must be 0 (automatic), 1, 4 or 16");
+    }
+    const long long total_jobs = n_local * (64 >> job_shift);
+    const long long cpb = 64 >> job_shift;
+    const long long bpj = (nch + cpb - 1) / cpb;
+    if (total_jobs >= (1ll << 31) || total_jobs * bpj >= (1ll << 40))
+        return fail(-5, "render too large for one call: %lld pixel-block jobs", total_jobs);
+    K.total_jobs = (unsigned)total_jobs; K.bpj = (unsigned)bpj; K.job_shift = (unsigned)job_shift;
+    make_udiv((unsigned)bpj, &K.div_bpj_m, &K.div_bpj_s);
     const long long max_useful = (total_jobs * bpj + 3) / 4;          // one batch per wave, 4 waves per block
     if (grid > max_useful) grid = max_useful;
     if (grid < 1) grid = 1;
@@ -438,6 +452,7 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     *rec_out = rec;
     rec->n_spheres = scene->n; rec->n_chunks = nch; rec->grid = (int)grid;
     HIP_TRY(hipMemsetAsync(rec->ctr, 0, sizeof(rtw::DevCounters), stream));
+    HIP_TRY(hipMemsetAsync(&rec->ctr->t_first, 0xff, sizeof(unsigned long long), stream));
     // pixels of other shards read 0 in the full-frame layout (the sum over the shards is the image)
     if (K.out_layout == 0 && p->shard_count > 1)
         HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)p->width * p->height * 3 * sizeof(T), stream));
@@ -465,6 +480,11 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
         fprintf(stderr, "[rtw phase profile] wave-cycles: pull %.1f%%  sample+scatter finish %.1f%%  scan-pass1/level1 %.1f%%  extract/level2 %.1f%%  resolve %.1f%%  shade %.1f%%  (total %.3g)\n",
                 100 * c.phase[0] / tot, 100 * c.phase[1] / tot, 100 * c.phase[2] / tot, 100 * c.phase[4] / tot,
                 100 * c.phase[5] / tot, 100 * c.phase[3] / tot, tot);
+    }
+    if (getenv("RTW_DRAIN_PROFILE") && c.n_waves) {
+        const double span = (double)(c.t_last - c.t_first) * 1e-5, mean_end = ((double)c.t_end_sum / (double)c.n_waves - (double)c.t_first) * 1e-5;
+        fprintf(stderr, "[rtw drain profile] %llu waves: kernel span %.2f ms, mean wave end at %.2f ms -> %.2f ms (%.1f %%) of idle wave slots at the end of the queue\n",
+                (unsigned long long)c.n_waves, span, mean_end, span - mean_end, 100.0 * (span - mean_end) / span);
     }
     agg->samples += c.samples;
     agg->segments += c.segments;

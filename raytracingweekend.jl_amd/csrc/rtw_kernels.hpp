@@ -2,11 +2,11 @@
 // pixel accumulation and the gamma / store of src/render.jl:40.  gfx950 only; wave = 64 lanes.
 //
 // Work decomposition
-//   job   = one 4x4 pixel block (a quarter of an 8x8 tile) for ALL its sample chunks.  Jobs come
+//   job   = one 4x4 pixel block of an 8x8 tile (2x2 or 1 pixel for small shards) for ALL its sample chunks.  Jobs come
 //           from one global queue (one atomic per job); a job is owned by ONE workgroup, whose
 //           LDS holds the block's 16 x 3 pixel accumulators while the job is in flight.
 //   item  = (pixel, chunk): `chunk_spp` consecutive samples of one pixel drawn from the item's own
-//           Xoroshiro128+ stream.  64 consecutive items = 16 pixels x 4 chunks = one wave batch,
+//           Xoroshiro128+ stream.  64 consecutive items = job pixels x (64 / job pixels) chunks = one wave batch,
 //           taken from the workgroup's ticket counter in LDS.
 //   lane  = persistent worker.  It owns one item at a time, starts its next sample the moment
 //           its path ends (no lock-step on path length) and takes the next item when its chunk
@@ -22,8 +22,7 @@
 
 namespace rtw {
 
-#define RTW_JOB_PX 16        // pixels per job (4x4 block)
-#define RTW_JOB_CPB 4        // chunks per 64-item batch
+#define RTW_JOB_PX 16        // slot capacity: pixels per job are 16 (4x4 block), 4 (2x2) or 1 -- KParams::job_shift
 #define RTW_NSLOT 6          // jobs in flight per workgroup
 #define RTW_SLOT_FREE 0xffffffffu
 #define RTW_SLOT_OPENING 0xfffffffeu
@@ -37,7 +36,9 @@ struct KParams {
     int shard_index, shard_count;
     int tiles_i, tiles_j;  // 8x8 tiles along rows (i) and columns (j)
     unsigned total_jobs;   // 4 * (tiles owned by this shard)
-    unsigned bpj;          // batches per job = ceil(n_chunks / RTW_JOB_CPB)
+    unsigned bpj;          // batches per job = ceil(n_chunks / (64 >> job_shift))
+    unsigned job_shift;    // log2(pixels per job): 4, 2 or 0.  A batch = (1 << job_shift) pixels x (64 >> job_shift) chunks.
+                           // Smaller jobs = finer load balance at the end of the queue (small shards); same image.
     // exact unsigned division by loop-invariant divisors (host: make_udiv):
     // n / d == (umulhi(n, m) + ((n - umulhi(n, m)) >> 1)) >> s   for every 32-bit n
     unsigned div_bpj_m, div_bpj_s, div_tiles_m, div_tiles_s;
@@ -51,6 +52,8 @@ struct DevCounters {
     unsigned long long segments;
     unsigned long long samples;
     unsigned long long phase[8];   // RTW_PHASE_PROFILE=1 only: wave-cycles per phase (s_memtime)
+    unsigned long long t_first, t_last, t_end_sum, n_waves;   // wall clock (100 MHz) of the first wave start, the last wave
+                                                              // end and the sum of all wave ends: the end-of-queue drain
 };
 
 // One job in flight: the 16 pixels' accumulators and the bookkeeping of the open/retire protocol.
@@ -136,10 +139,10 @@ __device__ __forceinline__ void fx_accumulate(unsigned long long *a, double r, d
 // The store of one finished job (src/render.jl:40, src/vec.jl:22): lane = (pixel, channel).
 template <typename T>
 __device__ RTW_RARE_ATTR void store_job(const KParams &P, const JobSlot *S, unsigned lane, T *__restrict__ out) {
-    if (lane < 3u * RTW_JOB_PX) {
-        const unsigned px = lane & (RTW_JOB_PX - 1u), ch = lane >> 4;
+    const unsigned px = lane & ((1u << P.job_shift) - 1u), ch = lane >> P.job_shift, side = P.job_shift >> 1;
+    if (ch < 3u) {
         if ((S->valid >> px) & 1u) {
-            const int i0 = S->i_base + (int)(px & 3u), j0 = S->j_base + (int)(px >> 2);
+            const int i0 = S->i_base + (int)(px & ((1u << side) - 1u)), j0 = S->j_base + (int)(px >> side);
             double v = fx_to_double(S->acc[px][2 * ch], S->acc[px][2 * ch + 1]);
             if (S->acc[px][6] != 0ull) v = __builtin_nan("");
             v = v / (double)P.spp;
@@ -161,14 +164,15 @@ __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned la
         if (lane == 0) g = atomicAdd(&ctr->next_job, 1u);
         g = uniform(g);
         if (g >= P.total_jobs) { g = RTW_JOB_EOF; break; }
-        k = g >> 2;                                          // job = 4 * (local tile) + quadrant
-        const unsigned q = g & 3u;
+        const unsigned side = P.job_shift >> 1, sub_shift = 6u - P.job_shift, bps_shift = 3u - side;
+        k = g >> sub_shift;                                  // job = (local tile) * (blocks per tile) + block
+        const unsigned q = g & ((1u << sub_shift) - 1u);
         const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
         const unsigned tj = udiv_magic(t, P.div_tiles_m, P.div_tiles_s), ti = t - tj * (unsigned)P.tiles_i;
-        i_base = (int)(ti * 8u + (q & 1u) * 4u);
-        j_base = (int)(tj * 8u + (q >> 1) * 4u);
-        const int i0 = i_base + (int)(lane & 3u), j0 = j_base + (int)((lane >> 2) & 3u);
-        valid = (unsigned)__ballot(lane < RTW_JOB_PX && i0 < P.height && j0 < P.width);
+        i_base = (int)(ti * 8u + ((q & ((1u << bps_shift) - 1u)) << side));
+        j_base = (int)(tj * 8u + ((q >> bps_shift) << side));
+        const int i0 = i_base + (int)(lane & ((1u << side) - 1u)), j0 = j_base + (int)((lane >> side) & ((1u << side) - 1u));
+        valid = (unsigned)__ballot(lane < (1u << P.job_shift) && i0 < P.height && j0 < P.width);
         if (valid) break;                                    // (blocks entirely outside the image are skipped)
     }
     if (g != RTW_JOB_EOF) {
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
     }
     __syncthreads();
 
+    const unsigned long long t_wave_start = wall_clock64();
     // ---- wave-uniform state ----
     unsigned pool_next = 0, pool_end = 0;   // unassigned items [pool_next, pool_end) of the wave's current batch
     unsigned pool_slot = 0, pool_b = 0;
@@ -313,16 +318,17 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
                     }
                 }
             }
-            // hand out items of the wave's batch: item p = (pixel p & 15, chunk 4 b + (p >> 4))
+            // hand out items of the wave's batch: item p = (pixel p mod job_px, chunk (64 / job_px) b + p / job_px)
             const unsigned long long take_mask = __ballot(need && alive);
             if (take_mask && pool_next < pool_end) {
                 const unsigned rank = (unsigned)__popcll(take_mask & ((1ull << lane) - 1ull));
                 const unsigned p = pool_next + rank;
                 if (need && alive && p < pool_end) {
                     const JobSlot *S = &sh->slot[pool_slot];
-                    const unsigned px = p & 15u, chunk = pool_b * RTW_JOB_CPB + (p >> 4);
+                    const unsigned px = p & ((1u << P.job_shift) - 1u), chunk = pool_b * (64u >> P.job_shift) + (p >> P.job_shift);
                     if ((int)chunk < P.n_chunks && ((S->valid >> px) & 1u)) {
-                        const int i0 = S->i_base + (int)(px & 3u), j0 = S->j_base + (int)(px >> 2);
+                        const unsigned side = P.job_shift >> 1;
+                        const int i0 = S->i_base + (int)(px & ((1u << side) - 1u)), j0 = S->j_base + (int)(px >> side);
                         const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
                         rng_stream(P.seed, pix, chunk, rng);
                         const int s0 = (int)chunk * P.chunk_spp;
@@ -372,8 +378,9 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
             }
             const JobSlot *S = &sh->slot[(ref_depth & 127u) >> 4];
             const unsigned px = ref_depth & 15u;
-            su = (T)S->uv[px >> 2] + du;                  // T(j / W) + du,       src/render.jl:26,37
-            sv = (T)S->uv[4 + (px & 3u)] + dv;            // T((H - i) / H) + dv, src/render.jl:27,37
+            const unsigned side = P.job_shift >> 1;
+            su = (T)S->uv[px >> side] + du;                            // T(j / W) + du,       src/render.jl:26,37
+            sv = (T)S->uv[4 + (px & ((1u << side) - 1u))] + dv;        // T((H - i) / H) + dv, src/render.jl:27,37
             new_sample = true;
             jitter = true;
             samples_left -= 1;
@@ -419,6 +426,11 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
     if (lane == 0) {
         atomicAdd(&ctr->segments, n_segments);
         atomicAdd(&ctr->samples, n_samples);
+        const unsigned long long t_wave_end = wall_clock64();
+        atomicMin(&ctr->t_first, t_wave_start);
+        atomicMax(&ctr->t_last, t_wave_end);
+        atomicAdd(&ctr->t_end_sum, t_wave_end);
+        atomicAdd(&ctr->n_waves, 1ull);
     }
 }
 

@@ -29,7 +29,7 @@ def _random_spheres_case(rtw, oracle, T, width, spp, depth=50, n_chunks=0):
     cam = rtw.t_cam1(elem_type=T)
     h = rtw.image_height(width)
     return dict(flat=flat, cam=_cam_dict(cam, oracle), image=np.zeros(1, T), width=width, height=h, spp=spp,
-                depth=depth, seed=1, n_chunks=n_chunks or min(spp, 128)), cam
+                depth=depth, seed=1, n_chunks=n_chunks or oracle.default_n_chunks(spp)), cam
 
 
 # ---- Float64 at BASELINE configs[4] geometry -------------------------------------------------------
@@ -56,7 +56,7 @@ def test_full_size_f64_4k_properties(oracle, rtw):
 def test_f64_more_chunks_than_a_batch(oracle, rtw):
     """Float64, 37 spp in 37 chunks (10 batches per job, the last one ragged), odd image size"""
     T = np.float64
-    g, cam = _random_spheres_case(rtw, oracle, T, 100, 37, depth=16)
+    g, cam = _random_spheres_case(rtw, oracle, T, 100, 37, depth=16, n_chunks=37)
     img, st = gpu_render(g)
     ref, ost = oracle.render(g["flat"], cam, 100, g["height"], 37, T=T, max_depth=16, seed=1, n_chunks=37)
     assert np.array_equal(img, ref) and st.segments == ost["segments"]
@@ -132,8 +132,8 @@ def test_two_streams_in_flight_and_compact_layout(rtw):
     n_local = (tiles_i * tiles_j - index + count - 1) // count
     comp = torch.full((n_local * 64 * 3,), -7.0, dtype=torch.float32, device="cuda:0")
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    dr.render_into(full.data_ptr(), W, 64, depth=16, seed=1, n_chunks=64, stream=s1.cuda_stream)
-    dr.render_into(comp.data_ptr(), W, 64, depth=16, seed=1, n_chunks=64, shard_index=index, shard_count=count,
+    dr.render_into(full.data_ptr(), W, 64, depth=16, seed=1, n_chunks=g["n_chunks"], stream=s1.cuda_stream)
+    dr.render_into(comp.data_ptr(), W, 64, depth=16, seed=1, n_chunks=g["n_chunks"], shard_index=index, shard_count=count,
                    stream=s2.cuda_stream, compact=True)
     st2 = dr.stats()                                           # the second call's counters
     s1.synchronize(); s2.synchronize()
@@ -195,6 +195,24 @@ def test_exact_accumulation_unit(oracle):
         s, bad = oracle.fx_sum(x[i])
         assert y[i, 1] == bad, i
         assert (np.isnan(y[i, 0]) and np.isnan(s)) or y[i, 0] == s, (i, y[i, 0], s)
+
+
+@pytest.mark.parametrize("name", ["cfg2_random_320x180_64spp_d16_f32", "random_64x36_8spp_d50_f64", "metal4_96x54_8spp_d16_f32"])
+def test_job_size_does_not_change_the_image(name):
+    """rtw_params.job_pixels (1, 4 or 16 pixels per work-queue job; 0 = automatic) is scheduling
+    granularity only: same image, same segment count, also for a shard and in group-cull mode"""
+    g = load_golden(name)
+    for jp in (1, 4, 16):
+        img, st = gpu_render(g, job_pixels=jp)
+        assert np.array_equal(img, g["image"]) and st.segments == g["segments"], jp
+    a, _ = gpu_render(g, job_pixels=1, shard_index=1, shard_count=5, flags=1)
+    b, _ = gpu_render(g, job_pixels=16, shard_index=1, shard_count=5)
+    assert np.array_equal(a, b)
+    # ragged size, fewer chunks than a one-pixel job's batch holds
+    w = 50
+    x, _ = gpu_render(g, width=w, height=(w * 9) // 16, spp=5, n_chunks=5, job_pixels=1)
+    y, _ = gpu_render(g, width=w, height=(w * 9) // 16, spp=5, n_chunks=5, job_pixels=16)
+    assert np.array_equal(x, y)
 
 
 def test_image_is_invariant_under_chunk_order_and_slots(oracle, rtw):

@@ -14,7 +14,7 @@ T = np.float64 if dt == "f64" else np.float32
 H = R.image_height(W)
 R.reseed(); scene = R.scene_random_spheres(elem_type=T); cam = R.t_cam1(elem_type=T)
 flat = R.flatten_scene(scene, T)
-nch = min(spp, 128); cs = -(-spp // nch); nch = -(-spp // cs)
+nch = O.default_n_chunks(spp); cs = -(-spp // nch); nch = -(-spp // cs)
 rays = []
 for arg in sys.argv[5:]:
     i0, j0 = [int(x) for x in arg.split(",")]
