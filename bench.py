@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--emulate-shard-of", type=int, default=0,
                     help="analysis only: on ONE GPU render shard 0 of N (what each rank of an N-GPU run does)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration per leg")
+    ap.add_argument("--collective", choices=["reduce", "gather"], default="reduce",
+                    help="N > 1: reduce = sum of zero-padded full frames onto rank 0 (BASELINE configs[3]); "
+                         "gather = each rank sends only its compact tile-major shard (1/N of a frame)")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,9 +109,10 @@ def main():
                 if args.emulate_shard_of > 1:
                     idx, cnt = 0, args.emulate_shard_of
                 renderer.render_into(fb.data_ptr(), W, spp, depth=depth_, seed=1, n_chunks=args.chunks, shard_index=idx,
-                                     shard_count=cnt, stream=stream.cuda_stream, group_cull=cull)
+                                     shard_count=cnt, stream=stream.cuda_stream, group_cull=cull,
+                                     compact=args.collective == "gather")
                 return fb
-            R.render_sharded(shard, W)                      # renders this rank's tiles, one reduce onto rank 0
+            R.render_sharded(shard, W, mode=args.collective)    # renders this rank's tiles, ONE collective onto rank 0
             if rec is not None:
                 rec.append(renderer.stats())                # waits for this rank's kernel (HIP events on `stream`)
         for _ in range(n_warm):
@@ -231,7 +235,7 @@ def main():
             "config": {"workload": f"scene_random_spheres ({n_spheres} spheres, reseed!() seed 1), t_cam1, {W}x{H}, {spp} spp, "
                                    f"depth {depth}, {jl} ({cfg_name})",
                        "scan": "group_cull (opt-in)" if args.group_cull else "plain linear scan over all spheres (reference algorithm)",
-                       "parallelism": f"tile-sharded x{world}" + (" + 1 RCCL reduce" if world > 1 else ""),
+                       "parallelism": f"tile-sharded x{world}" + (f" + 1 RCCL {args.collective}" if world > 1 else ""),
                        "rng": f"Xoroshiro128+ per (pixel, chunk), {stats[0]['n_chunks']} chunks/pixel; exact fixed-point pixel accumulation"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_16t": cpu16, "accelerated": accel,
             "end_to_end": end_to_end, "depth16": depth16,

@@ -20,7 +20,7 @@ from .scenes import (  # noqa: F401
     scene_random_spheres, t_cam1, t_cam2, t_default_cam,
 )
 from .render import DeviceRenderer, render, last_stats  # noqa: F401
-from .shard import owned_pixel_mask, render_sharded  # noqa: F401
+from .shard import compact_elems, compact_to_frame_index, local_tile_count, owned_pixel_mask, render_sharded  # noqa: F401
 from . import imageio  # noqa: F401
 
 __all__ = [
@@ -29,5 +29,6 @@ __all__ = [
     "default_camera", "flatten_scene", "image_height",
     "scene_2_spheres", "scene_4_spheres", "scene_blue_red_spheres", "scene_diel_spheres",
     "scene_random_spheres", "t_cam1", "t_cam2", "t_default_cam",
-    "DeviceRenderer", "render", "last_stats", "owned_pixel_mask", "render_sharded",
+    "DeviceRenderer", "render", "last_stats", "owned_pixel_mask", "render_sharded", "compact_elems",
+    "compact_to_frame_index", "local_tile_count",
 ]

@@ -157,6 +157,23 @@ def test_two_streams_in_flight_and_compact_layout(rtw):
     dr.close()
 
 
+def test_gather_mode_assembles_the_frame(rtw):
+    """shard.render_sharded(mode="gather") on one rank: compact render + indexed copy = the golden frame"""
+    import torch
+    T = np.float32
+    g = load_golden("metal4_96x54_8spp_d16_f32")
+    dr = rtw.DeviceRenderer(rtw.scene_4_spheres(elem_type=T), rtw.t_default_cam(elem_type=T), device=0)
+    buf = torch.empty(96 * 54 * 3 + 192 * 8, dtype=torch.float32, device="cuda:0")     # larger than needed is fine
+
+    def shard(idx, cnt):
+        dr.render_into(buf.data_ptr(), 96, g["spp"], depth=g["depth"], seed=g["seed"], n_chunks=g["n_chunks"], shard_index=idx,
+                       shard_count=cnt, stream=torch.cuda.current_stream().cuda_stream, compact=True)
+        return buf
+    frame = rtw.render_sharded(shard, 96, mode="gather")
+    assert np.array_equal(frame.cpu().numpy().reshape(96, 54, 3).transpose(1, 0, 2), g["image"])
+    dr.close()
+
+
 def test_stats_after_shutdown_reports_no_render(rtw):
     from rtw_amd import _capi
     L = _capi.lib()
