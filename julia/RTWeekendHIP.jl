@@ -36,11 +36,18 @@ end
 CCamera(c::Camera{T}) where T = CCamera{T}(Tuple(c.origin), Tuple(c.lower_left_corner), Tuple(c.horizontal),
                                            Tuple(c.vertical), Tuple(c.u), Tuple(c.v), Tuple(c.w), c.lens_radius)
 
-# rtw_params
+# rtw_params (ABI version 2)
 struct CParams
     width::Int32; height::Int32; spp::Int32; max_depth::Int32
     seed::UInt64
     n_chunks::Int32; shard_index::Int32; shard_count::Int32; device::Int32; gamma::Int32; flags::Int32
+    n_devices::Int32; job_pixels::Int32
+    device_ids::Ptr{Int32}
+end
+
+function __init__()
+    v = ccall((:rtw_abi_version, LIB), Cint, ())
+    v == 2 || error("librtw_hip.so has ABI version $v; this shim binds version 2 (include/rtw_hip.h)")
 end
 
 matkind(::Lambertian) = Int32(0)
@@ -57,14 +64,16 @@ matparam(m::Dielectric{T}) where T = m.ir
 last_error() = unsafe_string(ccall((:rtw_last_error, LIB), Cstring, ()))
 
 """
-    render(scene, cam, image_width=400, n_samples=1; depth=16, seed=1, n_chunks=0, device=-1, group_cull=false)
+    render(scene, cam, image_width=400, n_samples=1; depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, group_cull=false)
 
-Drop-in for `RayTracingWeekend.render` (src/render.jl:8-44) on one MI355X.  Keyword extras only.
+Drop-in for `RayTracingWeekend.render` (src/render.jl:8-44) on MI355X.  Keyword extras only.
 `depth=16` is the reference's hard-wired `ray_color` default (src/ray_color.jl:14).
+`devices=:all` uses every visible GPU, `devices=[0, 1, 2]` the listed ones (the 8x8 tiles are dealt
+round-robin to the devices inside the library; the image is identical for any device list).
 `group_cull=true` selects the opt-in accelerated scan (RTW_FLAG_GROUP_CULL): same image bit for bit.
 """
 function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=1;
-                depth=16, seed=1, n_chunks=0, device=-1, group_cull=false) where T <: Union{Float32,Float64}
+                depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, group_cull=false) where T <: Union{Float32,Float64}
     image_height = image_width ÷ (16//9)                       # src/render.jl:11-12
     n = length(scene)
     cx = Vector{T}(undef, n); cy = similar(cx); cz = similar(cx); r = similar(cx)
@@ -80,8 +89,12 @@ function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=
     end
     img = Matrix{RGB{T}}(undef, image_height, image_width)      # column-major H x W, 3 x T per pixel
     ccam = Ref(CCamera(cam))
-    params = Ref(CParams(image_width, image_height, n_samples, depth, seed, n_chunks, 0, 1, device, 1, group_cull ? 1 : 0))
-    rc = GC.@preserve cx cy cz r kind ar ag ab param img begin
+    ids = devices isa AbstractVector ? Int32.(devices) : Int32[]
+    n_devices = devices === :all ? -1 : (length(ids) > 1 ? length(ids) : 0)
+    length(ids) == 1 && (device = ids[1])
+    rc = GC.@preserve cx cy cz r kind ar ag ab param img ids begin
+        params = Ref(CParams(image_width, image_height, n_samples, depth, seed, n_chunks, 0, 1, device, 1, group_cull ? 1 : 0,
+                             n_devices, 0, length(ids) > 1 ? pointer(ids) : Ptr{Int32}(C_NULL)))
         cscene = Ref(CScene{T}(n, pointer(cx), pointer(cy), pointer(cz), pointer(r), pointer(kind),
                                pointer(ar), pointer(ag), pointer(ab), pointer(param)))
         if T === Float32

@@ -110,3 +110,58 @@ def test_image_writers_and_diff(rtw, tmp_path):
     assert r["identical"] and r["max_abs"] == 0 and r["psnr_db"] == float("inf")
     r = rtw.imageio.diff_report(img, img + np.float32(1e-3))
     assert not r["identical"] and abs(r["max_abs"] - 1e-3) < 1e-6 and r["frac_within_2e3"] == 1.0
+
+
+def test_julia_shim_struct_layouts_match_the_c_abi():
+    """julia/RTWeekendHIP.jl cannot be executed here (no julia): at least its `struct` declarations must
+    lay out exactly like include/rtw_hip.h (= the ctypes mirrors the GPU tests drive), field by field."""
+    from rtw_amd import _capi
+    src = open(os.path.join(ROOT, "julia", "RTWeekendHIP.jl")).read()
+    size_of = {"Int32": 4, "UInt64": 8, "Ptr{T}": 8, "Ptr{Int32}": 8, "T": None, "NTuple{3,T}": None}
+
+    def fields(name):
+        body = re.search(r"struct %s(?:\{T\})?\n(.*?)\nend" % name, src, re.S).group(1)
+        out = []
+        for part in re.split(r"[;\n]", body):
+            part = part.split("#")[0].strip()
+            if part:
+                f, t = [x.strip() for x in part.split("::")]
+                out.append((f, t))
+        return out
+
+    def layout(flds, tsize):
+        off, res = 0, []
+        for f, t in flds:
+            size = {"T": tsize, "NTuple{3,T}": 3 * tsize}.get(t, size_of.get(t))
+            align = tsize if t in ("T", "NTuple{3,T}") else size
+            off = (off + align - 1) // align * align
+            res.append((f, off, size))
+            off += size
+        return res
+
+    for jl, ct, tsize in (("CParams", _capi.Params, 4), ("CScene", _capi.SceneF32, 4), ("CScene", _capi.SceneF64, 8),
+                          ("CCamera", _capi.CameraF32, 4), ("CCamera", _capi.CameraF64, 8)):
+        lay = layout(fields(jl), tsize)
+        cf = [(n, getattr(ct, n).offset, getattr(ct, n).size) for n, _ in ct._fields_]
+        assert [(o, s) for _, o, s in lay] == [(o, s) for _, o, s in cf], (jl, lay, cf)
+        assert [n for n, _, _ in lay] == [n for n, _, _ in cf], jl
+    assert "v == 2 ||" in src and _capi.ABI_VERSION == 2
+
+
+def test_check_julia_kat_detects_a_wrong_assumption(tmp_path):
+    """tools/check_julia_kat.py (tier T2 in one command): the self-test passes; a tampered dump is caught"""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_julia_kat.py")
+    r = subprocess.run([sys.executable, tool, "--self-test", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ALL PASS" in r.stdout and r.stdout.count("PASS") >= 16, r.stdout[-2000:] + r.stderr[-2000:]
+    txt = (tmp_path / "julia_kat.txt").read_text().splitlines()
+    k = next(i for i, line in enumerate(txt) if line.startswith("rng_f32 seed=1"))
+    vals = txt[k].split(": ")[1].split()
+    vals[3] = "0.5"                                              # "Julia" extracted a different Float32
+    txt[k] = "rng_f32 seed=1: " + " ".join(vals)
+    (tmp_path / "julia_kat.txt").write_text("\n".join(txt) + "\n")
+    r = subprocess.run([sys.executable, tool, str(tmp_path / "julia_kat.txt")], capture_output=True, text=True)
+    assert r.returncode == 1 and "rand(rng, Float32): low 23 bits" in r.stdout
+    line = next(x for x in r.stdout.splitlines() if x.startswith("rand(rng, Float32)"))
+    assert "FAIL" in line and r.stdout.count("FAIL") == 2        # that item and the summary line

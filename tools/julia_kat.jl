@@ -2,46 +2,70 @@
 # unverified third-party restatements (DESIGN.md section 3, tier T2).  This image has no julia.
 #
 #   julia --project=/path/to/RayTracingWeekend.jl -t1 tools/julia_kat.jl > julia_kat.txt
+#   python tools/check_julia_kat.py julia_kat.txt          # prints PASS/FAIL per [UNVERIFIED] item
 #
-# then compare with tests/golden/rng_provisional.npz and the oracle's REF_SERIAL render:
-#   1. Xoroshiro128Plus(seed) state after construction, first 16 UInt64 / Float32 / Float64
+# Output = one record per line, `key: values...`; floats are printed with %.9g (Float32) / %.17g
+# (Float64), which round-trips exactly.  The two images go to julia_render_2spheres_96x54_16spp_<T>.bin
+# next to the text file (raw column-major RGB{T}, what check_julia_kat.py reads back).
+#   1. Xoroshiro128Plus(seed): state after construction, first 16 UInt64 / Float32 / Float64
 #   2. scene_random_spheres(elem_type=T) after reseed!()  (SoA dump)
 #   3. default_camera presets (22 scalars)
-#   4. render(scene_2_spheres, default cam, 96, 16) with ONE thread (the reference's own smoke
-#      render, test/runtests.jl:194) -> compare with oracle REF_SERIAL, ref_threads = 1
+#   4. StaticArrays normalize / dot, Base tand, and hit(::Sphere) on fixed rays (@fastmath contraction)
+#   5. render(scene_2_spheres, default cam, 96, 16) with ONE thread (the reference's own smoke
+#      render, test/runtests.jl:194) -> compare with the oracle's REF_SERIAL, ref_threads = 1
 using RayTracingWeekend, StaticArrays, RandomNumbers.Xorshifts, Printf
 
+fmt(x::Float32) = @sprintf("%.9g", x)
+fmt(x::Float64) = @sprintf("%.17g", x)
+fmt(x::Integer) = string(x)
+vals(xs) = join((fmt(x) for x in xs), " ")
+
+println("julia_version: ", VERSION, " nthreads: ", Threads.nthreads())
 for seed in (1, 2)
     r = Xoroshiro128Plus(seed)
-    @printf("rng seed=%d state=(%016x,%016x)\n", seed, r.x, r.y)
-    println("  u64: ", join([@sprintf("%016x", rand(r, UInt64)) for _ in 1:16], " "))
-    r = Xoroshiro128Plus(seed); println("  f32: ", join([@sprintf("%.9g", rand(r, Float32)) for _ in 1:16], " "))
-    r = Xoroshiro128Plus(seed); println("  f64: ", join([@sprintf("%.17g", rand(r, Float64)) for _ in 1:16], " "))
+    @printf("rng_state seed=%d: %016x %016x\n", seed, r.x, r.y)
+    println("rng_u64 seed=$seed: ", join([@sprintf("%016x", rand(r, UInt64)) for _ in 1:16], " "))
+    r = Xoroshiro128Plus(seed); println("rng_f32 seed=$seed: ", vals([rand(r, Float32) for _ in 1:16]))
+    r = Xoroshiro128Plus(seed); println("rng_f64 seed=$seed: ", vals([rand(r, Float64) for _ in 1:16]))
 end
 
+kindof(::Lambertian) = 0
+kindof(::Metal) = 1
+kindof(::Dielectric) = 2
 for T in (Float32, Float64)
     reseed!()
     s = scene_random_spheres(elem_type=T)
-    println("scene_random_spheres $T n=", length(s))
+    println("scene $T n: ", length(s))
     for (i, h) in enumerate(s)
         m = h.mat
-        @printf("  %d c=(%.9g,%.9g,%.9g) r=%.9g %s", i, h.center..., h.radius, nameof(typeof(m)))
-        m isa Lambertian && @printf(" albedo=(%.9g,%.9g,%.9g)", m.albedo...)
-        m isa Metal && @printf(" albedo=(%.9g,%.9g,%.9g) fuzz=%.9g", m.albedo..., m.fuzz)
-        m isa Dielectric && @printf(" ir=%.9g", m.ir)
-        println()
+        alb = m isa Dielectric ? SVector{3,T}(1, 1, 1) : m.albedo
+        par = m isa Metal ? m.fuzz : (m isa Dielectric ? m.ir : zero(T))
+        println("sphere $T $(i-1): ", vals((h.center..., h.radius)), " ", kindof(m), " ", vals((alb..., par)))
     end
     for (name, cam) in (("t_default_cam", default_camera(SA{T}[0, 0, 0])),
-                        ("t_cam1", default_camera([13, 2, 3], [0, 0, 0], [0, 1, 0], 20, 16 / 9, 0.1, 10.0; elem_type=T)))
-        println("camera $name $T: ", cam)
+                        ("t_cam1", default_camera([13, 2, 3], [0, 0, 0], [0, 1, 0], 20, 16 / 9, 0.1, 10.0; elem_type=T)),
+                        ("t_cam2", default_camera([3, 3, 2], [0, 0, -1], [0, 1, 0], 20, 16 / 9, 2.0, sqrt(27.0); elem_type=T)))
+        println("camera $name $T: ", vals((cam.origin..., cam.lower_left_corner..., cam.horizontal..., cam.vertical...,
+                                           cam.u..., cam.v..., cam.w..., cam.lens_radius)))
     end
-    # normalize / dot conventions of StaticArrays
     v = SA{T}[0.3, -0.7, 0.2]
-    println("normalize $T: ", normalize(v), "  dot: ", v ⋅ SA{T}[0.1, 0.2, 0.3], " tand(10): ", tand(T(10)))
+    println("normalize $T: ", vals(normalize(v)))
+    println("dot $T: ", fmt(v ⋅ SA{T}[0.1, 0.2, 0.3]))
+    println("tand $T: ", vals((tand(T(10)), tand(T(45)), tand(T(20) / 2))))
+    # hit(::Sphere) on fixed rays: pins what @fastmath contracts in src/hit.jl:13-29
+    rays = [(SA{T}[13, 2, 3], normalize(SA{T}[-13, -2.2, -3.1])), (SA{T}[0, 0, 0], normalize(SA{T}[0.1, -0.05, -1])),
+            (SA{T}[0.3, 0.1, -0.6], normalize(SA{T}[-0.2, 0.4, -1])), (SA{T}[4, 1.5, 2], normalize(SA{T}[-1, -0.4, -0.55]))]
+    sph = [Sphere(SA{T}[0, -1000, -1], T(1000), Lambertian(SA{T}[0.5, 0.5, 0.5])), Sphere(SA{T}[0, 0, -1], T(0.5), Lambertian(SA{T}[0.5, 0.5, 0.5])),
+           Sphere(SA{T}[0, 0, -1], T(-0.4), Dielectric(T(1.5))), Sphere(SA{T}[0, 1, 0], T(1), Dielectric(T(1.5)))]
+    for (ri, (o, d)) in enumerate(rays), (si, sp) in enumerate(sph)
+        rec = RayTracingWeekend.hit(sp, RayTracingWeekend.Ray(o, d), T(1e-4), typemax(T))
+        println("hit $T $ri $si: ", vals((o..., d..., sp.center..., sp.radius)), " -> ",
+                rec === nothing ? "miss" : vals((rec.t, rec.p..., rec.n⃗..., rec.front_face ? 1 : 0)))
+    end
     Threads.nthreads() == 1 || @warn "run with -t1: the image depends on the thread count (SURVEY F6)"
     img = render(scene_2_spheres(elem_type=T), default_camera(SA{T}[0, 0, 0]), 96, 16)
     open("julia_render_2spheres_96x54_16spp_$(T).bin", "w") do io
         write(io, reinterpret(T, vec(img)))
     end
-    println("render $T mean=", sum(reinterpret(T, vec(img))) / (3 * length(img)))
+    println("render $T mean: ", fmt(sum(reinterpret(T, vec(img))) / T(3 * length(img))))
 end
