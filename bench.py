@@ -19,8 +19,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   (157.3 TF) or FP64 (78.6 TF) vector peak; `traffic` = HBM bytes per launch from
                   the committed PMC passes (profiles/), plus the algorithmic HBM figure vs 8 TB/s.
   cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
-                  bounded sample of the same workload (same image, fewer spp); `cpu_baseline_16t`
-                  is the same with 16 threads (the north star's comparison point).
+                  bounded sample of the same workload (same image, fewer spp): the faster of a
+                  16-thread leg (`cpu_baseline_16t`, the north star's comparison point) and an
+                  all-threads leg (`cpu_baseline_all_threads`).
   accelerated  -- the opt-in RTW_FLAG_GROUP_CULL mode (same image bit for bit), reported separately.
   end_to_end   -- one call of the host-buffer entry point rtw_render_* (scene upload, render,
                   D2H of the image: the PCIe-inclusive rate; never `value`).
@@ -204,6 +205,7 @@ def main():
                     "peak_GBs": HBM_PEAK_GBS, "frac": round(alg_bytes / k_s / 1e9 / HBM_PEAK_GBS, 8)},
         }
         cpu = cpu16 = None
+        legs = []
         if world == 1 and not args.no_cpu_baseline:
             import rtw_oracle as O
             O.build()
@@ -221,9 +223,12 @@ def main():
                 return {"value": round(W * H * s_spp / tc / 1e6, 4), "unit": "Msamples/s", "cores": nthr, "kind": "port",
                         "sample": f"same scene/camera/{W}x{H}/depth {depth}/{jl}, {s_spp} spp ({tc:.1f} s), oracle/ C port with OpenMP; "
                                   f"the Julia reference cannot run here (no julia in the image)"}
-            cpu = cpu_leg(threads)
-            if threads > 16:
-                cpu16 = cpu_leg(16)
+            # the GPU boxes are shared hosts (2 x EPYC 9575F, cgroup-limited): all-threads runs are often SLOWER than
+            # 16 threads there.  Both legs are reported; `cpu_baseline` is the faster one (the fairer baseline).
+            legs = [cpu_leg(16)] if threads >= 16 else []
+            legs.append(cpu_leg(threads))
+            cpu16 = legs[0] if threads >= 16 else None
+            cpu = max(legs, key=lambda d: d["value"])
         cfg_name = {("f32", 1920, 1000, 50): "BASELINE.json configs[2]" if world == 1 else "BASELINE.json configs[3]",
                     ("f64", 3840, 1000, 50): "BASELINE.json configs[4]" + (", one GPU" if world == 1 else "")}.get(
             (args.dtype, W, spp, depth), "not a BASELINE config")
@@ -237,7 +242,8 @@ def main():
                        "scan": "group_cull (opt-in)" if args.group_cull else "plain linear scan over all spheres (reference algorithm)",
                        "parallelism": f"tile-sharded x{world}" + (f" + 1 RCCL {args.collective}" if world > 1 else ""),
                        "rng": f"Xoroshiro128+ per (pixel, chunk), {stats[0]['n_chunks']} chunks/pixel; exact fixed-point pixel accumulation"},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_16t": cpu16, "accelerated": accel,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_16t": cpu16,
+            "cpu_baseline_all_threads": (legs[-1] if world == 1 and not args.no_cpu_baseline else None), "accelerated": accel,
             "end_to_end": end_to_end, "depth16": depth16,
         }
         if cpu:

@@ -7,13 +7,14 @@ hard-wires 16 through ``ray_color``'s default, src/ray_color.jl:14), ``seed``, `
 ``device``.  All compute happens in librtw_hip.so; there is no CPU fallback.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
 from . import _capi
 from .structs import Camera, flatten_scene, image_height
 
-_last_stats = None
+_tls = threading.local()      # last_stats() is per calling thread, like rtw_stats() itself
 
 
 def _as_image(flat, height, width):
@@ -28,7 +29,6 @@ def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chun
     ``group_cull=True`` selects the opt-in accelerated scan (same image, include/rtw_hip.h).
     ``devices``: ``"all"`` or a list of HIP ordinals -- the 8x8 tiles are dealt to those devices
     inside the library (``rtw_params.n_devices/device_ids``); the image is the same for any list."""
-    global _last_stats
     if not isinstance(cam, Camera):
         raise TypeError("cam must be a Camera")
     T = cam.elem_type
@@ -48,14 +48,14 @@ def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chun
     _capi.check(fn(C.byref(S), C.byref(Cm), C.byref(P), out.ctypes.data_as(C.c_void_p)))
     st = _capi.Stats()
     _capi.check(L.rtw_stats(C.byref(st)))
-    _last_stats = {k: getattr(st, k) for k, _ in st._fields_}
+    _tls.stats = {k: getattr(st, k) for k, _ in st._fields_}
     del keep
     return _as_image(out, height, int(image_width))
 
 
 def last_stats():
-    """Counters/timings of the most recent render (include/rtw_hip.h ``rtw_stats_t``)."""
-    return _last_stats
+    """Counters/timings of the calling thread's most recent render (include/rtw_hip.h ``rtw_stats_t``)."""
+    return getattr(_tls, "stats", None)
 
 
 class DeviceRenderer:

@@ -132,6 +132,7 @@ def test_two_streams_in_flight_and_compact_layout(rtw):
     n_local = (tiles_i * tiles_j - index + count - 1) // count
     comp = torch.full((n_local * 64 * 3,), -7.0, dtype=torch.float32, device="cuda:0")
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())   # the fill of `comp` runs on the default stream
     dr.render_into(full.data_ptr(), W, 64, depth=16, seed=1, n_chunks=g["n_chunks"], stream=s1.cuda_stream)
     dr.render_into(comp.data_ptr(), W, 64, depth=16, seed=1, n_chunks=g["n_chunks"], shard_index=index, shard_count=count,
                    stream=s2.cuda_stream, compact=True)

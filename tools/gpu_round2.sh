@@ -32,7 +32,7 @@ import csv, glob, collections, json, os
 out = {}
 for d in sorted(glob.glob("$O/pmc_*")):
     if not os.path.isdir(d): continue
-    c = collections.defaultdict(float); n = 0; dur = []
+    c = collections.defaultdict(float); dur = []
     for f in glob.glob(d + "/*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
             if "trace_kernel" in row["Kernel_Name"]: c[row["Counter_Name"]] += float(row["Counter_Value"])
@@ -42,4 +42,16 @@ for d in sorted(glob.glob("$O/pmc_*")):
     out[os.path.basename(d)] = {"counters": dict(c), "launches": len(dur), "kernel_ns": dur}
 json.dump(out, open("$O/pmc_summary.json", "w"), indent=1)
 for k, v in out.items(): print(k, v["launches"], {a: round(b, 3) for a, b in v["counters"].items()}, [round(x / 1e6, 2) for x in v["kernel_ns"]])
+# HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section:
+# on gfx950 it reports half of the bytes of wide reads; WRITE_SIZE is taken as is -- uncalibrated)
+tr = {}
+for key, tag in (("f32_1920x1080_1000spp_d50_plain", "f32"), ("f32_1920x1080_1000spp_d50_cull", "f32_cull"), ("f64_3840x2160_1000spp_d50_plain", "f64")):
+    f, w = out.get("pmc_%s_fetch" % tag), out.get("pmc_%s_write" % tag)
+    if f and w and f["launches"] and w["launches"]:
+        fb = f["counters"].get("FETCH_SIZE", 0) / f["launches"] * 1024
+        wb = w["counters"].get("WRITE_SIZE", 0) / w["launches"] * 1024
+        tr[key] = {"hbm_bytes_per_launch": int(2 * fb + wb), "fetch_size_bytes_raw": int(fb), "write_size_bytes": int(wb),
+                   "source": "rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE / --pmc GRBM_GUI_ACTIVE WRITE_SIZE, one launch each (tools/gpu_round2.sh)"}
+json.dump(tr, open("$O/hbm_traffic.json", "w"), indent=1)
+print(json.dumps(tr, indent=1))
 PY
