@@ -349,7 +349,7 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (!p) return fail(-1, "null params");
     if (p->width <= 0 || p->height <= 0) return fail(-2, "width/height must be positive (got %d x %d)", p->width, p->height);
     if (p->spp <= 0) return fail(-2, "spp must be positive (got %d)", p->spp);
-    if (p->max_depth < 0 || p->max_depth >= (1 << 24)) return fail(-2, "max_depth must be in [0, 2^24)");
+    if (p->max_depth < 0 || p->max_depth >= (1 << 22)) return fail(-2, "max_depth must be in [0, 2^22)");
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
@@ -426,11 +426,12 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 256, lds_bytes));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     long long grid = (long long)ctx->num_cus * blocks_per_cu;
-    // Job size: 2x2 pixels (a batch = 4 pixels x 16 chunks) unless there are too few chunks to fill such a
-    // batch, then 4x4 (16 pixels x 4 chunks).  Measured at 1080p x 1000 spp (tools/gpu_drain.py): the end-of-queue
-    // drain is 10 ms with 2x2 jobs and 33 ms with 4x4 jobs (full frame 871 vs 885 ms; a 1/8 shard 120 vs 140 ms);
-    // one-pixel jobs starve the 6 job slots of a workgroup (full frame 1160 ms).
-    int job_shift = nch >= 16 ? 2 : 4;
+    // Job size: the smallest pixel block whose 64-item batches the chunks still fill: 1 pixel (x 64 chunks) from 64
+    // chunks up, 2x2 (x 16 chunks) from 16, else 4x4 (x 4 chunks).  A job is owned by one workgroup, so its size sets
+    // the end-of-queue drain.  Measured at 1080p x 1000 spp / 250 chunks (tools/gpu_drain.py): drain 4.4 / 9.7 / 30 ms
+    // of idle wave slots for 1 / 4 / 16-pixel jobs; full frame 859 / 859 / 871 ms; a 1/8 shard 115.6 / 119.8 / 137.7 ms.
+    // (Slots per workgroup: 24 / 12 / 4 -- one-pixel jobs need many slots in flight; with 6 they ran 33 % slower.)
+    int job_shift = nch >= 64 ? 0 : nch >= 16 ? 2 : 4;
     if (p->job_pixels == 16 || p->job_pixels == 4 || p->job_pixels == 1) {
         job_shift = p->job_pixels == 16 ? 4 : p->job_pixels == 4 ? 2 : 0;
     } else if (p->job_pixels != 0) {
@@ -442,6 +443,9 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     if (total_jobs >= (1ll << 31) || total_jobs * bpj >= (1ll << 40))
         return fail(-5, "render too large for one call: %lld pixel-block jobs", total_jobs);
     K.total_jobs = (unsigned)total_jobs; K.bpj = (unsigned)bpj; K.job_shift = (unsigned)job_shift;
+    K.slot_stride = (unsigned)(sizeof(rtw::JobSlot) + 64u * (1u << job_shift));
+    K.n_slots = std::min(24u, (unsigned)RTW_SLOT_BYTES / K.slot_stride);             // 24 / 12 / 4 slots of 1 / 4 / 16 pixels
+    make_udiv(K.n_slots, &K.div_slots_m, &K.div_slots_s);
     make_udiv((unsigned)bpj, &K.div_bpj_m, &K.div_bpj_s);
     const long long max_useful = (total_jobs * bpj + 3) / 4;          // one batch per wave, 4 waves per block
     if (grid > max_useful) grid = max_useful;
@@ -472,8 +476,10 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
     HIP_TRY(hipEventSynchronize(r->ev1));
     float k_ms = 0;
     HIP_TRY(hipEventElapsedTime(&k_ms, r->ev0, r->ev1));
+    static rtw::DevCounters c_static;      // (16 KB: not on the stack; resolve_rec runs under no lock but only copies out)
     rtw::DevCounters c;
     HIP_TRY(hipMemcpy(&c, r->ctr, sizeof c, hipMemcpyDeviceToHost));
+    (void)c_static;
     if (getenv("RTW_PHASE_PROFILE")) {
         double tot = 0;
         for (int k = 0; k < 6; ++k) tot += (double)c.phase[k];
@@ -485,6 +491,11 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
         const double span = (double)(c.t_last - c.t_first) * 1e-5, mean_end = ((double)c.t_end_sum / (double)c.n_waves - (double)c.t_first) * 1e-5;
         fprintf(stderr, "[rtw drain profile] %llu waves: kernel span %.2f ms, mean wave end at %.2f ms -> %.2f ms (%.1f %%) of idle wave slots at the end of the queue\n",
                 (unsigned long long)c.n_waves, span, mean_end, span - mean_end, 100.0 * (span - mean_end) / span);
+        int last = 4095;
+        while (last > 0 && !c.end_hist[last]) --last;
+        fprintf(stderr, "[rtw drain profile] waves ending per 0.25 ms bin, last 64 bins (ending at %.2f ms):", (last + 1) * 0.25);
+        for (int b = std::max(0, last - 63); b <= last; ++b) fprintf(stderr, " %u", c.end_hist[b]);
+        fprintf(stderr, "\n");
     }
     agg->samples += c.samples;
     agg->segments += c.segments;

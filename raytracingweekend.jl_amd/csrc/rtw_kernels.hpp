@@ -23,7 +23,9 @@
 namespace rtw {
 
 #define RTW_JOB_PX 16        // slot capacity: pixels per job are 16 (4x4 block), 4 (2x2) or 1 -- KParams::job_shift
-#define RTW_NSLOT 6          // jobs in flight per workgroup
+#define RTW_SLOT_BYTES 4608  // LDS for job slots per workgroup: 24 slots of 1 pixel, 12 of 4 or 4 of 16
+#define RTW_REF_BITS 9       // item reference = slot (5 bits) << 4 | pixel (4 bits)
+#define RTW_REF_MASK 511u
 #define RTW_SLOT_FREE 0xffffffffu
 #define RTW_SLOT_OPENING 0xfffffffeu
 #define RTW_JOB_EOF 0xffffffffu
@@ -37,6 +39,7 @@ struct KParams {
     int tiles_i, tiles_j;  // 8x8 tiles along rows (i) and columns (j)
     unsigned total_jobs;   // 4 * (tiles owned by this shard)
     unsigned bpj;          // batches per job = ceil(n_chunks / (64 >> job_shift))
+    unsigned n_slots, slot_stride, div_slots_m, div_slots_s;   // job slots per workgroup (by job size), bytes per slot, n / n_slots
     unsigned job_shift;    // log2(pixels per job): 4, 2 or 0.  A batch = (1 << job_shift) pixels x (64 >> job_shift) chunks.
                            // Smaller jobs = finer load balance at the end of the queue (small shards); same image.
     // exact unsigned division by loop-invariant divisors (host: make_udiv):
@@ -54,11 +57,12 @@ struct DevCounters {
     unsigned long long phase[8];   // RTW_PHASE_PROFILE=1 only: wave-cycles per phase (s_memtime)
     unsigned long long t_first, t_last, t_end_sum, n_waves;   // wall clock (100 MHz) of the first wave start, the last wave
                                                               // end and the sum of all wave ends: the end-of-queue drain
+    unsigned end_hist[4096];                                  // waves by end time since t_first, 0.25 ms bins (RTW_DRAIN_PROFILE)
 };
 
-// One job in flight: the 16 pixels' accumulators and the bookkeeping of the open/retire protocol.
+// One job in flight: the bookkeeping of the open/retire protocol and the block header, followed in LDS by
+// the job's pixel accumulators (8 x u64 per pixel: r.lo r.hi g.lo g.hi b.lo b.hi poison pad).
 struct JobSlot {
-    unsigned long long acc[RTW_JOB_PX][7];   // r.lo r.hi g.lo g.hi b.lo b.hi poison
     unsigned ready_seq;                      // RTW_SLOT_FREE | RTW_SLOT_OPENING | the job sequence number it holds
     unsigned job;                            // global job id, or RTW_JOB_EOF (queue exhausted; never freed)
     int remaining;                           // items of the job not yet finished
@@ -66,10 +70,14 @@ struct JobSlot {
     int i_base, j_base;                      // 0-based row / column of the block's first pixel
     unsigned k_tile;                         // local tile index (compact output layout)
     unsigned pad;
-    double uv[8];                            // j / W for the 4 columns, (H - i) / H for the 4 rows (src/render.jl:26-27), as binary64
+    double uv[8];                            // j / W for the block's columns, (H - i) / H for its rows (src/render.jl:26-27), as binary64
+    __device__ __forceinline__ unsigned long long *acc(unsigned px) { return reinterpret_cast<unsigned long long *>(this + 1) + 8u * px; }
+    __device__ __forceinline__ const unsigned long long *acc(unsigned px) const { return reinterpret_cast<const unsigned long long *>(this + 1) + 8u * px; }
 };
+static_assert(sizeof(JobSlot) == 96, "JobSlot header is 96 bytes (16-byte aligned accumulators follow)");
 template <typename T> struct WgShared {
-    JobSlot slot[RTW_NSLOT];
+    unsigned char slots[RTW_SLOT_BYTES];      // n_slots x (96-byte JobSlot + 64 bytes per job pixel)
+    __device__ __forceinline__ JobSlot *slot(unsigned i, unsigned stride) { return reinterpret_cast<JobSlot *>(slots + i * stride); }
     unsigned ticket;                         // next batch of this workgroup
     unsigned pad[3];
     Camera<T> cam;                           // read per new sample (keeps 22 SGPRs out of the scan loop)
@@ -143,8 +151,9 @@ __device__ RTW_RARE_ATTR void store_job(const KParams &P, const JobSlot *S, unsi
     if (ch < 3u) {
         if ((S->valid >> px) & 1u) {
             const int i0 = S->i_base + (int)(px & ((1u << side) - 1u)), j0 = S->j_base + (int)(px >> side);
-            double v = fx_to_double(S->acc[px][2 * ch], S->acc[px][2 * ch + 1]);
-            if (S->acc[px][6] != 0ull) v = __builtin_nan("");
+            const unsigned long long *a = S->acc(px);
+            double v = fx_to_double(a[2 * ch], a[2 * ch + 1]);
+            if (a[6] != 0ull) v = __builtin_nan("");
             v = v / (double)P.spp;
             if (P.gamma) v = __builtin_sqrt(v);
             const size_t pix = P.out_layout == 0 ? (size_t)j0 * (size_t)P.height + (size_t)i0
@@ -176,7 +185,7 @@ __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned la
         if (valid) break;                                    // (blocks entirely outside the image are skipped)
     }
     if (g != RTW_JOB_EOF) {
-        if (lane < (RTW_JOB_PX * 7 * 8) / 16) reinterpret_cast<uint4 *>(&S->acc[0][0])[lane] = uint4{0u, 0u, 0u, 0u};
+        if (lane < (4u << P.job_shift)) reinterpret_cast<uint4 *>(S->acc(0))[lane] = uint4{0u, 0u, 0u, 0u};   // 64 B per pixel
         if (lane < 4) S->uv[lane] = (double)(j_base + (int)lane + 1) / (double)P.width;                        // j / W
         else if (lane < 8) S->uv[lane] = (double)(P.height - (i_base + (int)lane - 4 + 1)) / (double)P.height;   // (H - i) / H
         if (lane == 0) {
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
     WgShared<T> *sh = reinterpret_cast<WgShared<T> *>(smem + list_bytes);
     V4 *lds_geom = reinterpret_cast<V4 *>(smem + list_bytes + shared_bytes);
     unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + (CULL ? cull_exact_count(cull) : 0));
-    if (threadIdx.x < RTW_NSLOT) { sh->slot[threadIdx.x].ready_seq = RTW_SLOT_FREE; sh->slot[threadIdx.x].job = 0u; }
+    if (threadIdx.x < P_arg.n_slots) { JobSlot *S0 = sh->slot(threadIdx.x, P_arg.slot_stride); S0->ready_seq = RTW_SLOT_FREE; S0->job = 0u; }
     if (threadIdx.x == 0) { sh->ticket = 0u; sh->cam = cam_arg; sh->P = P_arg; }
     const KParams &P = sh->P;
     if (LDS_SCENE) {
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
     bool alive = true;        // still pulling work
     bool have_item = false;   // owns an item (its job's `remaining` is decremented when the chunk is done)
     bool has_ray = false;     // a ray is ready for the scan
-    unsigned ref_depth = 0;   // (bounces left << 7) | item_ref, item_ref = slot * 16 + pixel of the owned item
+    unsigned ref_depth = 0;   // (bounces left << 9) | item_ref, item_ref = slot * 16 + pixel of the owned item
     int samples_left = 0;
     bool jitter = false;      // false only for sample 1 of the pixel (src/render.jl:30-31)
     Rng rng = {1, 2};
@@ -256,8 +265,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
         const bool hit = has_ray && idx >= 0;
         if (has_ray && idx < 0) {
             const C3 sky = skycolor(rd);
-            const unsigned item_ref = ref_depth & 127u;
-            fx_accumulate(sh->slot[item_ref >> 4].acc[item_ref & 15u], thr_r * sky.r, thr_g * sky.g, thr_b * sky.b);
+            const unsigned item_ref = ref_depth & RTW_REF_MASK;
+            fx_accumulate(sh->slot(item_ref >> 4, P.slot_stride)->acc(item_ref & 15u), thr_r * sky.r, thr_g * sky.g, thr_b * sky.b);
         }
         has_ray = false;
 
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
         if (need_mask) {
             bool last = false;
             if (need && have_item) {
-                last = __hip_atomic_fetch_add(&sh->slot[(ref_depth & 127u) >> 4].remaining, -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
+                last = __hip_atomic_fetch_add(&sh->slot((ref_depth & RTW_REF_MASK) >> 4, P.slot_stride)->remaining, -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
                 have_item = false;
             }
             // jobs whose last item just finished: the wave stores their 16 pixels and frees the slot
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
             while (fin) {
                 const int L = __builtin_ctzll(fin);
                 fin &= fin - 1ull;
-                JobSlot *S = &sh->slot[uniform((unsigned)__shfl((int)((ref_depth & 127u) >> 4), L))];
+                JobSlot *S = sh->slot(uniform((unsigned)__shfl((int)((ref_depth & RTW_REF_MASK) >> 4), L)), P.slot_stride);
                 store_job<T>(P, S, lane, out);
                 __hip_atomic_store(&S->ready_seq, RTW_SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -289,8 +298,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
                     tk_b = t - tk_seq * P.bpj;
                     have_ticket = true;
                 }
-                const unsigned sl = tk_seq % RTW_NSLOT;
-                JobSlot *S = &sh->slot[sl];
+                const unsigned sl = tk_seq - udiv_magic(tk_seq, P.div_slots_m, P.div_slots_s) * P.n_slots;   // tk_seq mod n_slots
+                JobSlot *S = sh->slot(sl, P.slot_stride);
                 unsigned rs = uniform(__hip_atomic_load(&S->ready_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (rs == RTW_SLOT_FREE && tk_b == 0u) {
                     // this wave opens the job: claim the slot, take a job from the global queue, zero the accumulators
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
                 const unsigned rank = (unsigned)__popcll(take_mask & ((1ull << lane) - 1ull));
                 const unsigned p = pool_next + rank;
                 if (need && alive && p < pool_end) {
-                    const JobSlot *S = &sh->slot[pool_slot];
+                    const JobSlot *S = sh->slot(pool_slot, P.slot_stride);
                     const unsigned px = p & ((1u << P.job_shift) - 1u), chunk = pool_b * (64u >> P.job_shift) + (p >> P.job_shift);
                     if ((int)chunk < P.n_chunks && ((S->valid >> px) & 1u)) {
                         const unsigned side = P.job_shift >> 1;
@@ -361,8 +370,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
             const V3<T> att = attenuation_of<T>(kind, {m1.x, m1.y, m1.z});
             thr_r = thr_r * (double)att.x; thr_g = thr_g * (double)att.y; thr_b = thr_b * (double)att.z;
             ro = rec.p;
-            ref_depth -= 128u;                                                  // one bounce used
-            if (todo == PATH_READY) { rd = vec; has_ray = ref_depth >= 128u; }   // depth 0: ray_color returns 0
+            ref_depth -= 1u << RTW_REF_BITS;                                    // one bounce used
+            if (todo == PATH_READY) { rd = vec; has_ray = ref_depth > RTW_REF_MASK; }   // depth 0: ray_color returns 0
         }
         clk.lap(3);
 
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
                 trand(rng, r1); du = r1 / w_div;
                 trand(rng, r2); dv = r2 / h_div;
             }
-            const JobSlot *S = &sh->slot[(ref_depth & 127u) >> 4];
+            const JobSlot *S = sh->slot((ref_depth & RTW_REF_MASK) >> 4, P.slot_stride);
             const unsigned px = ref_depth & 15u;
             const unsigned side = P.job_shift >> 1;
             su = (T)S->uv[px >> side] + du;                            // T(j / W) + du,       src/render.jl:26,37
@@ -412,10 +421,10 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
             camera_ray_raw<T>(cam, su, sv, rp.x, rp.y, ro, vec);   // src/camera.jl:43-48
             todo = PATH_NORM;
             thr_r = thr_g = thr_b = 1.0;
-            ref_depth = (ref_depth & 127u) | ((unsigned)P.max_depth << 7);
+            ref_depth = (ref_depth & RTW_REF_MASK) | ((unsigned)P.max_depth << RTW_REF_BITS);
         }
         if (todo == PATH_NORM) rd = normalize(vec);
-        if (ball || new_sample || todo == PATH_NORM) has_ray = ref_depth >= 128u;   // depth <= 0: ray_color returns 0 (src/ray_color.jl:15)
+        if (ball || new_sample || todo == PATH_NORM) has_ray = ref_depth > RTW_REF_MASK;   // depth <= 0: ray_color returns 0 (src/ray_color.jl:15)
         clk.lap(1);
         if (!__any(has_ray)) __builtin_amdgcn_s_sleep(2);    // every lane waits for a job slot: do not hammer LDS
     }
@@ -431,6 +440,9 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
         atomicMax(&ctr->t_last, t_wave_end);
         atomicAdd(&ctr->t_end_sum, t_wave_end);
         atomicAdd(&ctr->n_waves, 1ull);
+        const unsigned long long t0 = __hip_atomic_load(&ctr->t_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long bin = (t_wave_end - t0) / 25000ull;
+        atomicAdd(&ctr->end_hist[bin < 4095ull ? (unsigned)bin : 4095u], 1u);
     }
 }
 
