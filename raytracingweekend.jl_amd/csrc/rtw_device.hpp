@@ -308,6 +308,10 @@ __device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned l
 #define RTW_SPHERE_WORD 32
 #define RTW_SPHERE_TAIL 8
 template <typename T> struct DevScene {
+    const float *scan;   // what pass 1 streams through scalar loads (binary32 for BOTH precisions):
+                         //   Float32: geom itself, 4 floats per sphere (cx, cy, cz, r^2) -- the exact contract discriminant;
+                         //   Float64: 8 floats per sphere (cx, cy, cz, r^2, G, 0, 0, 0) rounded to binary32, for the
+                         //   conservative binary32 filter of hit_world (G = the sphere's share of the error margin)
     const typename Vec4<T>::type *geom;
     const typename Vec4<T>::type *mat0;
     const typename Vec4<T>::type *mat1;
@@ -326,7 +330,7 @@ __device__ __forceinline__ uint32_t sign_word(double x) { return (uint32_t)((uin
 
 template <typename T> struct ScanGroup;
 template <> struct ScanGroup<float> { static constexpr int N = 8; };    // 8 x 16 B = 2 x s_load_dwordx16
-template <> struct ScanGroup<double> { static constexpr int N = 4; };   // 4 x 32 B = 2 x s_load_dwordx16
+template <> struct ScanGroup<double> { static constexpr int N = 4; };   // 4 x 8 floats = 2 x s_load_dwordx16
 
 struct NoClock { __device__ __forceinline__ void lap(int) {} };
 
@@ -366,19 +370,57 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
                                          unsigned short *list, CLK &&clk = NoClock()) {
     using V4 = typename Vec4<T>::type;
     constexpr int G = ScanGroup<T>::N;
-    typedef const T __attribute__((address_space(4))) *cptr;    // constant address space: SMEM loads
-    cptr gs = (cptr)(uintptr_t)w.geom;
-    auto ldg = [&](int i) -> V4 { return V4{gs[4 * i], gs[4 * i + 1], gs[4 * i + 2], gs[4 * i + 3]}; };
+    constexpr bool F64 = sizeof(T) == 8;
+    constexpr int SW = F64 ? 8 : 4;                              // floats per sphere in the scan array
+    typedef const float __attribute__((address_space(4))) *cptr; // constant address space: SMEM loads
+    cptr gs = (cptr)(uintptr_t)w.scan;
+    struct Unit { float v[SW]; };
+    auto ldg = [&](int i) -> Unit {
+        Unit r;
+#pragma unroll
+        for (int j = 0; j < SW; ++j) r.v[j] = gs[SW * i + j];
+        return r;
+    };
     T closest = tmax;
     int idx = -1, cnt = 0;
-    V4 A[G], B[G];
+    Unit A[G], B[G];
 #pragma unroll
     for (int k = 0; k < G; ++k) A[k] = ldg(k);
-    // One sphere: discriminant + sign bit into the mask word (11 VALU ops).
-    auto test1 = [&](const V4 &sp, uint32_t &mask) {
-        T hb, disc;
-        sphere_disc<T>(sp.x, sp.y, sp.z, sp.w, o, d, hb, disc);
-        mask = __builtin_amdgcn_alignbit(mask, sign_word(disc), 31);
+    // Pass 1 only has to produce a SUPERSET of {spheres whose contract discriminant is >= 0}: pass 2 applies the
+    // exact test to every candidate.
+    //   Float32: the contract discriminant itself (10 VALU + 1 v_alignbit per sphere).
+    //   Float64: a conservative binary32 FILTER (12 VALU + 1 v_alignbit; an FP64 instruction costs two issue slots,
+    //   the exact form would be 10 x 2 + 1).  With o, c, d, r^2 rounded to binary32 (u = 2^-24) and the same
+    //   operation order, the computed  W = fma(hb, hb, fma(nc, 1 - 2^-18, G))  satisfies
+    //       W >= disc + 2^-18 |o - c|^2 + (G - 2^-18 r^2) - Err,
+    //       Err <= u [28.5 |o - c|^2 + 12.2 |c|^2 + 6.1 r^2 + 2 G]          for |d|^2 <= 1.001
+    //   (input rounding a = u (|o| + |c| + |o - c|) per component of o - c; 2 |hb| d(hb) <= u [11.3 |oc|^2 + 2.03 (|o|^2 +
+    //   |c|^2)]; d(nc) <= u [4.01 r^2 + 6.02 |oc|^2 + 2.01 (|o|^2 + |c|^2)]; the two final roundings <= u [2 r^2 +
+    //   3.01 |oc|^2 + 2 G]; |o|^2 <= 2 |oc|^2 + 2 |c|^2).  2^-18 = 64 u > 28.5 u, and the upload sets
+    //   G = 1.01 (2^-18 r^2 + 2^-20 |c|^2 + 2^-20 r^2) + 1e-30 (rounded up), so  disc >= 0  =>  W > 0: sign bit clear.
+    //   The binary64 roundings of the contract itself (<= 20 * 2^-53 (|oc| + r)^2) vanish in the slack.  Rays that
+    //   are not (nearly) unit, not finite or astronomically far take every sphere as a candidate (lane_ok).
+    [[maybe_unused]] bool lane_ok = true;
+    [[maybe_unused]] V3<float> of = {0, 0, 0}, df = {0, 0, 1};
+    if constexpr (F64) {
+        const double s2 = dot(d, d), o2 = dot(o, o);
+        lane_ok = s2 <= 1.001 && o2 < 1e30;                       // (false for NaN)
+        of = {(float)o.x, (float)o.y, (float)o.z};
+        df = {(float)d.x, (float)d.y, (float)d.z};
+    }
+    auto test1 = [&](const Unit &sp, uint32_t &mask) {
+        if constexpr (F64) {
+            const float ocx = of.x - sp.v[0], ocy = of.y - sp.v[1], ocz = of.z - sp.v[2];
+            const float hb = __builtin_fmaf(ocz, df.z, __builtin_fmaf(ocy, df.y, ocx * df.x));
+            const float nc = __builtin_fmaf(-ocz, ocz, __builtin_fmaf(-ocy, ocy, __builtin_fmaf(-ocx, ocx, sp.v[3])));
+            const float m = __builtin_fmaf(nc, 0.999996185302734375f /* 1 - 2^-18 */, sp.v[4]);
+            const float W = __builtin_fmaf(hb, hb, m);
+            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(W), 31);
+        } else {
+            T hb, disc;
+            sphere_disc<T>(sp.v[0], sp.v[1], sp.v[2], sp.v[3], o, d, hb, disc);
+            mask = __builtin_amdgcn_alignbit(mask, sign_word(disc), 31);
+        }
     };
     for (int base = 0; base < w.n_pad; base += RTW_SPHERE_WORD) {
         uint32_t mask = 0;
@@ -414,6 +456,7 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
         }
         clk.lap(2);
         uint32_t m = ~mask;                       // bit 31 = sphere `base`, bit 0 = sphere base+31
+        if constexpr (F64) { if (!lane_ok) m = 0xffffffffu; }                // no filter for this ray: every sphere
         if (left < RTW_SPHERE_WORD) m <<= (RTW_SPHERE_WORD - ngroups * G);   // partial word: align to bit 31
         auto push_first = [&]() {                 // append the lane's first remaining candidate of this word
             const int b = __clz((int)m);

@@ -160,6 +160,7 @@ struct rtw_scene_dev {
     int is_f64;
     int n, n_pad;
     void *geom, *mat0, *mat1;
+    void *scan;      // Float64: the binary32 filter array of pass 1 (8 floats per sphere); Float32: null (geom itself)
     // opt-in group-cull mode (RTW_FLAG_GROUP_CULL): cluster-major copies
     void *c_bound, *c_exact, *c_mat0, *c_mat1;
     unsigned short *c_orig;
@@ -330,6 +331,25 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     HIP_TRY(hipMemcpy(h->geom, geom.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->mat0, mat0.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->mat1, mat1.data(), bytes, hipMemcpyHostToDevice));
+    if (sizeof(T) == 8) {
+        // pass-1 filter data of hit_world<double>: centre and r^2 rounded to binary32 (to nearest) and the sphere's
+        // share G of the error margin, rounded up (derivation in rtw_device.hpp)
+        std::vector<float> f((size_t)n_alloc * 8, 0.0f);
+        for (int i = 0; i < n_alloc; ++i) {
+            float *q = &f[(size_t)i * 8];
+            q[0] = (float)geom[i].x; q[1] = (float)geom[i].y; q[2] = (float)geom[i].z; q[3] = (float)geom[i].w;
+            if (i < n) {
+                const double r2 = (double)geom[i].w, c2 = (double)geom[i].x * geom[i].x + (double)geom[i].y * geom[i].y + (double)geom[i].z * geom[i].z;
+                const double G = 1.01 * (std::ldexp(r2, -18) + std::ldexp(c2, -20) + std::ldexp(r2, -20)) + 1e-30;
+                float g = (float)G;
+                if ((double)g < G) g = std::nextafter(g, INFINITY);
+                if (!(c2 < 1e30) || !(r2 < 1e30)) g = INFINITY;                  // astronomically large: always a candidate
+                q[4] = g;
+            }                                                                     // padding spheres: r^2 = -1e30, G = 0
+        }
+        HIP_TRY(hipMalloc(&h->scan, f.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(h->scan, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (int rc = build_cull<T>(s, h.get())) return rc;
     *out = h.release();
     return 0;
@@ -403,6 +423,7 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     rtw::DevScene<T> S;
     using V4 = typename rtw::Vec4<T>::type;
     S.geom = (const V4 *)scene->geom; S.mat0 = (const V4 *)scene->mat0; S.mat1 = (const V4 *)scene->mat1;
+    S.scan = (const float *)(scene->scan ? scene->scan : scene->geom);
     S.n = scene->n; S.n_pad = scene->n_pad;
 
     // persistent grid: enough 256-thread blocks to fill every CU at the kernel's occupancy
@@ -635,13 +656,14 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
     DeviceCtx *ctx;
     if (int rc = get_ctx(dev, &ctx)) return rc;
     rtw_scene_handle h_raw = nullptr;
-    rtw::DevScene<T> S{nullptr, nullptr, nullptr, 0, 0};
+    rtw::DevScene<T> S{nullptr, nullptr, nullptr, nullptr, 0, 0};
     rtw::CullScene<T> CS;
     memset(&CS, 0, sizeof CS);
     if (needs_scene) {
         if (int rc = upload_scene<T>(scene, dev, &h_raw)) return rc;
         using V4 = typename rtw::Vec4<T>::type;
         S.geom = (const V4 *)h_raw->geom; S.mat0 = (const V4 *)h_raw->mat0; S.mat1 = (const V4 *)h_raw->mat1;
+        S.scan = (const float *)(h_raw->scan ? h_raw->scan : h_raw->geom);
         S.n = h_raw->n; S.n_pad = h_raw->n_pad;
         CS = cull_scene_of<T>(h_raw);
     }
@@ -706,7 +728,7 @@ int rtw_scene_free(rtw_scene_handle h) {
     if (!h) return 0;
     DeviceGuard guard;
     (void)hipSetDevice(h->device);
-    void *ptrs[] = {h->geom, h->mat0, h->mat1, h->c_bound, h->c_exact, h->c_mat0, h->c_mat1, h->c_orig};
+    void *ptrs[] = {h->geom, h->mat0, h->mat1, h->scan, h->c_bound, h->c_exact, h->c_mat0, h->c_mat1, h->c_orig};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete h;
     return 0;

@@ -282,6 +282,23 @@ def _stress_rays(rng, flat, m, T, scale):
     nrm = np.sqrt((d.astype(T) ** 2).sum(1, dtype=T)).astype(T)
     nrm[nrm == 0] = 1
     d = (d / nrm[:, None]).astype(T)
+    if n > 0:
+        # grazing rays: the line passes at distance r (1 + eps) from a centre, eps from -1e-3 to +1e-3 through 0 in
+        # both precisions' rounding range -- the Float64 scan's binary32 pass-1 filter must never lose a candidate
+        tang = rng.random(m) < 0.2
+        nt = int(tang.sum())
+        k2 = rng.integers(0, n, nt)
+        c2 = np.stack([flat["cx"][k2], flat["cy"][k2], flat["cz"][k2]], 1).astype(np.float64)
+        dd = rng.normal(size=(nt, 3)); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        perp = np.cross(dd, rng.normal(size=(nt, 3))); perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+        eps = rng.choice([0.0, 1e-15, -1e-15, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3], nt)
+        rr = np.abs(flat["r"][k2].astype(np.float64))
+        back = rng.uniform(0.5, 40.0, nt) * np.maximum(rr, 1.0)
+        o[tang] = (c2 + perp * (rr * (1.0 + eps))[:, None] - dd * back[:, None]).astype(T)
+        d[tang] = dd.astype(T)
+        nrm = np.sqrt((d.astype(T) ** 2).sum(1, dtype=T)).astype(T)
+        nrm[nrm == 0] = 1
+        d = (d / nrm[:, None]).astype(T)
     # the reference does not renormalise dielectric reflections (src/material.jl:48): directions drift away from
     # unit length along internal-reflection chains; the scans must agree with the oracle for those rays as well
     off = rng.random(m) < 0.15
