@@ -190,17 +190,23 @@ def main():
                 traffic, traffic_src = tr[key]["hbm_bytes_per_launch"], tr[key].get("source")
         except Exception:
             pass
+        if args.group_cull:
+            achieved_tflops = float("nan")          # the cull mode skips tests: a VALU fraction of never-executed tests would be meaningless
         roofline = {
             "bound": "valu_" + ("fp64" if args.dtype == "f64" else "fp32"), "kernel": f"rtw::trace_kernel<{'double' if args.dtype == 'f64' else 'float'}>",
-            "achieved": round(achieved_tflops, 3), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved_tflops / peak, 4),
+            "achieved": None if args.group_cull else round(achieved_tflops, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": None if args.group_cull else round(achieved_tflops / peak, 4),
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
             "traffic_source": traffic_src,
             "kernel_ms": round(k_s * 1e3, 3), "tests_per_launch": int(tests_per_launch),
-            "flop_per_test": FLOP_PER_TEST, "segments_per_sample": round(all_segments / (samples_per_step * shard_div * args.steps), 4),
+            "flop_per_test": FLOP_PER_TEST, "segments_per_sample": round(all_segments / (samples_per_step * args.steps), 4),
             "note": "peak = MI355X vector peak of the arithmetic type (FP32 157.3 TF from MI355X_MICROARCH.md; FP64 78.6 TF from the "
-                    "datasheet); the path has no dense contraction, so no MFMA.  The bare 11-instruction test loop tops out at "
-                    "0.58 of the FP32 peak on this chip (tools/ubench_issue.hip: 2.6 cycles per VALU instruction at 7-8 waves/SIMD)",
+                    "datasheet); the path has no dense contraction, so no MFMA.  achieved = counted ray-sphere tests x 17 flop / kernel time.  "
+                    + ("Float64: every sphere is tested every segment, but pass 1 of the scan is a conservative binary32 filter "
+                       "(12 FP32 instructions per sphere, rigorous margin) and only its candidates get the exact binary64 test, so the "
+                       "algorithmic FP64 flops are not all executed as FP64 instructions (DESIGN.md 6.1)" if args.dtype == "f64" else
+                       "The kernel issues 2.25 cycles per VALU instruction; the test loop is 11 instructions per sphere = 76 % of the "
+                       "instruction stream (DESIGN.md 6.3)"),
             "hbm": {"algorithmic_bytes": int(alg_bytes), "achieved_GBs": round(alg_bytes / k_s / 1e9, 4),
                     "peak_GBs": HBM_PEAK_GBS, "frac": round(alg_bytes / k_s / 1e9 / HBM_PEAK_GBS, 8)},
         }

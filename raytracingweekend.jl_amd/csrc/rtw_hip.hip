@@ -447,12 +447,15 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 256, lds_bytes));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     long long grid = (long long)ctx->num_cus * blocks_per_cu;
-    // Job size: the smallest pixel block whose 64-item batches the chunks still fill: 1 pixel (x 64 chunks) from 64
-    // chunks up, 2x2 (x 16 chunks) from 16, else 4x4 (x 4 chunks).  A job is owned by one workgroup, so its size sets
-    // the end-of-queue drain.  Measured at 1080p x 1000 spp / 250 chunks (tools/gpu_drain.py): drain 4.4 / 9.7 / 30 ms
-    // of idle wave slots for 1 / 4 / 16-pixel jobs; full frame 859 / 859 / 871 ms; a 1/8 shard 115.6 / 119.8 / 137.7 ms.
+    // Job size.  A job is owned by one workgroup, so its size sets the end-of-queue drain; smaller jobs also store the
+    // image in smaller pieces (more partial-line writes).  2x2 pixels (a batch = 4 pixels x 16 chunks) when the chunks
+    // fill such batches, else 4x4 (x 4 chunks); ONE pixel (x 64 chunks) when a workgroup would otherwise see fewer than
+    // 150 jobs (small frames, shards of a multi-GPU render).  Measured at 1080p x 1000 spp / 250 chunks
+    // (tools/gpu_drain.py): drain 4.4 / 9.7 / 30 ms of idle wave slots for 1 / 4 / 16-pixel jobs; full frame 859 / 859 /
+    // 871 ms; a 1/8 shard 115.6 / 119.8 / 137.7 ms; HBM writes 148 / 72 / 45 MB per frame.
     // (Slots per workgroup: 24 / 12 / 4 -- one-pixel jobs need many slots in flight; with 6 they ran 33 % slower.)
-    int job_shift = nch >= 64 ? 0 : nch >= 16 ? 2 : 4;
+    int job_shift = nch >= 16 ? 2 : 4;
+    if (nch >= 64 && n_local * 16 < 150 * grid) job_shift = 0;
     if (p->job_pixels == 16 || p->job_pixels == 4 || p->job_pixels == 1) {
         job_shift = p->job_pixels == 16 ? 4 : p->job_pixels == 4 ? 2 : 0;
     } else if (p->job_pixels != 0) {
