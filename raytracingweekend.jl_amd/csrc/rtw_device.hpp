@@ -368,7 +368,6 @@ __device__ __forceinline__ void resolve_candidates(SRC src, V3<T> o, V3<T> d, T 
 template <typename T, int STRIDE, typename SRC, typename CLK = NoClock>
 __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o, V3<T> d, T tmin, T tmax, T &t_hit,
                                          unsigned short *list, CLK &&clk = NoClock()) {
-    using V4 = typename Vec4<T>::type;
     constexpr int G = ScanGroup<T>::N;
     constexpr bool F64 = sizeof(T) == 8;
     constexpr int SW = F64 ? 8 : 4;                              // floats per sphere in the scan array

@@ -500,10 +500,8 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
     HIP_TRY(hipEventSynchronize(r->ev1));
     float k_ms = 0;
     HIP_TRY(hipEventElapsedTime(&k_ms, r->ev0, r->ev1));
-    static rtw::DevCounters c_static;      // (16 KB: not on the stack; resolve_rec runs under no lock but only copies out)
-    rtw::DevCounters c;
+    rtw::DevCounters c;                    // (16 KB incl. the drain histogram)
     HIP_TRY(hipMemcpy(&c, r->ctr, sizeof c, hipMemcpyDeviceToHost));
-    (void)c_static;
     if (getenv("RTW_PHASE_PROFILE")) {
         double tot = 0;
         for (int k = 0; k < 6; ++k) tot += (double)c.phase[k];
