@@ -79,11 +79,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # RTW_BENCH_ONE_DEVICE=1 (test aid for one-GPU boxes): every rank uses cuda:0 and the collective runs over gloo --
+    # exercises the N > 1 control flow of this script (sharding, collective, max-over-ranks timing), not RCCL itself
+    one_device = os.environ.get("RTW_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     T = np.float64 if args.dtype == "f64" else np.float32
     tT = torch.float64 if args.dtype == "f64" else torch.float32
