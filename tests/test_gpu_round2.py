@@ -354,7 +354,7 @@ def test_group_cull_identical_at_headline_scale(rtw):
 def test_t3_statistical_parity_with_ref_serial(oracle, rtw):
     """GPU (PIXEL_STREAM streams) vs the oracle in REF_SERIAL mode -- one Xoroshiro128+ per Julia
     thread, static row blocks, serial consumption, reference product order: exactly what
-    src/render.jl:19-23 does with `julia -t 90` -- on the headline scene at 160x90, 1024 spp,
+    src/render.jl:19-23 does with `julia -t 180` -- on the headline scene at 320x180, 1024 spp,
     depth 16 (the reference's depth), linear radiance (gamma off).
 
     Both are unbiased estimators of the same image, so with A = GPU seed 1, B = GPU seed 2 and
@@ -366,7 +366,7 @@ def test_t3_statistical_parity_with_ref_serial(oracle, rtw):
       * no structured residual: the largest |8x8 block mean| of D2 is <= 1.6 x that of D1
     """
     T = np.float32
-    W, H, spp, depth = 160, 90, 1024, 16
+    W, H, spp, depth = 320, 180, 1024, 16          # (artefacts of the same comparison: profiles/r02_t3_*.png / .json)
     g, cam = _random_spheres_case(rtw, oracle, T, W, spp, depth=depth)
     A, _ = gpu_render(g, gamma=0)
     B, _ = gpu_render(g, gamma=0, seed=2)
