@@ -44,11 +44,22 @@ int fail(int code, const char *fmt, ...) {
             return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// for calls whose failure cannot be acted upon (frees on cleanup paths): RTW_DEBUG=1 reports them on stderr
+#define HIP_IGNORE(expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            static const bool dbg_ = getenv("RTW_DEBUG") != nullptr;                          \
+            if (dbg_) fprintf(stderr, "[rtw debug] %s -> %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError();            /* do not leave it for a later hipGetLastError() check */ \
+        }                                                                                     \
+    } while (0)
+
 // restores the caller's current device when an entry point returns
 struct DeviceGuard {
     int prev = -1;
     DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    ~DeviceGuard() { if (prev >= 0) HIP_IGNORE(hipSetDevice(prev)); }
 };
 
 // ---- per-render record: device counters + the events that time the trace kernel ---------------
@@ -57,12 +68,13 @@ struct RenderRec {
     rtw::DevCounters *ctr = nullptr;     // device memory
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool used = false;                   // ev1 has been recorded at least once
+    bool done = true;                    // the kernel recorded by ev1 is known to have finished (no hipEventQuery needed)
     bool owned = false;                  // referenced by some thread's "last render"
     int n_spheres = 0, n_chunks = 0, grid = 0;
     ~RenderRec() {
-        if (ctr) (void)hipFree(ctr);
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
+        if (ctr) HIP_IGNORE(hipFree(ctr));
+        if (ev0) HIP_IGNORE(hipEventDestroy(ev0));
+        if (ev1) HIP_IGNORE(hipEventDestroy(ev1));
     }
 };
 
@@ -107,7 +119,10 @@ int acquire_rec(DeviceCtx *ctx, RenderRec **out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     for (auto &r : ctx->recs) {
         if (r->owned) continue;
-        if (r->used && hipEventQuery(r->ev1) != hipSuccess) continue;
+        if (r->used && !r->done) {
+            if (hipEventQuery(r->ev1) != hipSuccess) { (void)hipGetLastError(); continue; }   // still in flight
+            r->done = true;
+        }
         r->owned = true;
         *out = r.get();
         return 0;
@@ -486,11 +501,12 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
         HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)p->width * p->height * 3 * sizeof(T), stream));
     HIP_TRY(hipEventRecord(rec->ev0, stream));
     if (total_jobs > 0) {
+        (void)hipGetLastError();           // (hipEventQuery's hipErrorNotReady in acquire_rec must not be mistaken for a launch failure)
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, CS, (T *)d_out, rec->ctr);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(rec->ev1, stream));
-    rec->used = true;
+    rec->used = true; rec->done = false;
     return 0;
 }
 
@@ -498,6 +514,7 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
 int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipEventSynchronize(r->ev1));
+    r->done = true;
     float k_ms = 0;
     HIP_TRY(hipEventElapsedTime(&k_ms, r->ev0, r->ev1));
     rtw::DevCounters c;                    // (16 KB incl. the drain histogram)
@@ -544,8 +561,9 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
 // one shard of a host-buffer render: upload, render, copy back.  layout 0 -> `out` is the full frame;
 // compact (multi-device) -> the shard's tiles are scattered into the full frame on the host.
 template <typename T, typename SceneT, typename CamT>
-int render_host_shard(const SceneT *scene, const CamT *cam, rtw_params p, T *out, bool compact, RenderRec **rec_out, char *err, size_t err_len) {
+int render_host_shard(const SceneT *scene, const CamT *cam, rtw_params p, T *out, bool compact, rtw_stats_t *stats_out, char *err, size_t err_len) {
     int rc = 0;
+    RenderRec *rec = nullptr;
     rtw_scene_handle h_raw = nullptr;
     void *d_out = nullptr;
     T *staging = nullptr;
@@ -561,7 +579,7 @@ int render_host_shard(const SceneT *scene, const CamT *cam, rtw_params p, T *out
         if (compact) p.flags |= RTW_FLAG_COMPACT_TILES;
         if (elems == 0) break;
         if ((e = hipMalloc(&d_out, elems * sizeof(T))) != hipSuccess) { rc = fail((int)e, "hipMalloc(image) failed: %s", hipGetErrorString(e)); break; }
-        if ((rc = launch_render<T>(h_raw, cam, &p, d_out, stream, rec_out))) break;
+        if ((rc = launch_render<T>(h_raw, cam, &p, d_out, stream, &rec))) break;
         if (!compact) {
             e = hipMemcpyAsync(out, d_out, elems * sizeof(T), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -585,11 +603,18 @@ int render_host_shard(const SceneT *scene, const CamT *cam, rtw_params p, T *out
                 }
             }
         }
+        // the kernel has finished (stream synchronised above): read its counters while the stream still exists
+        memset(stats_out, 0, sizeof *stats_out);
+        rc = resolve_rec(rec, stats_out);
     } while (0);
+    if (rec) {                                     // hand the record back: nothing refers to it any more
+        DeviceCtx *ctx = nullptr;
+        if (get_ctx(rec->device, &ctx) == 0) { std::lock_guard<std::mutex> lk(ctx->mu); if (rc == 0) rec->done = true; rec->owned = false; }
+    }
     if (rc && err) snprintf(err, err_len, "%s", g_err);
-    if (staging) (void)hipHostFree(staging);
-    if (d_out) (void)hipFree(d_out);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (staging) HIP_IGNORE(hipHostFree(staging));
+    if (d_out) HIP_IGNORE(hipFree(d_out));
+    if (stream) HIP_IGNORE(hipStreamDestroy(stream));
     if (h_raw) rtw_scene_free(h_raw);
     return rc;
 }
@@ -617,28 +642,34 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
     if (devs.size() <= 1) {
         rtw_params q = *p;
         if (devs.size() == 1) q.device = devs[0];
-        RenderRec *rec = nullptr;
-        int rc = render_host_shard<T>(scene, cam, q, out, false, &rec, nullptr, 0);
-        if (rec) g_last.recs.push_back(rec);
+        int rc = render_host_shard<T>(scene, cam, q, out, false, &g_last.agg, nullptr, 0);
+        g_last.resolved = rc == 0;
         return rc;
     }
     if (p->shard_count != 1) return fail(-2, "n_devices > 1 cannot be combined with shard_index/shard_count");
     // one host thread per device renders tiles t = r (mod N) and scatters them into `out`; tiles are disjoint
     const int N = (int)devs.size();
     std::vector<int> rcs(N, 0);
-    std::vector<RenderRec *> recs(N, nullptr);
+    std::vector<rtw_stats_t> sts(N);
     std::vector<std::vector<char>> errs(N, std::vector<char>(512, 0));
     std::vector<std::thread> th;
     for (int r = 0; r < N; ++r) {
         th.emplace_back([&, r]() {
             rtw_params q = *p;
             q.device = devs[r]; q.shard_index = r; q.shard_count = N; q.n_devices = 0; q.device_ids = nullptr;
-            rcs[r] = render_host_shard<T>(scene, cam, q, out, true, &recs[r], errs[r].data(), errs[r].size());
+            memset(&sts[r], 0, sizeof sts[r]);
+            rcs[r] = render_host_shard<T>(scene, cam, q, out, true, &sts[r], errs[r].data(), errs[r].size());
         });
     }
     for (auto &t : th) t.join();
-    for (int r = 0; r < N; ++r) if (recs[r]) g_last.recs.push_back(recs[r]);
     for (int r = 0; r < N; ++r) if (rcs[r]) return fail(rcs[r], "device %d (shard %d of %d): %s", devs[r], r, N, errs[r].data());
+    rtw_stats_t &a = g_last.agg;                       // sums over the devices; times: the maximum
+    for (int r = 0; r < N; ++r) {
+        a.samples += sts[r].samples; a.segments += sts[r].segments; a.sphere_tests += sts[r].sphere_tests;
+        a.kernel_ms = std::max(a.kernel_ms, sts[r].kernel_ms); a.total_ms = std::max(a.total_ms, sts[r].total_ms);
+        a.n_chunks = sts[r].n_chunks; a.grid_blocks = std::max(a.grid_blocks, sts[r].grid_blocks); a.block_threads = 256;
+    }
+    g_last.resolved = true;
     return 0;
 }
 
@@ -696,12 +727,13 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
         (e = hipMemcpy(d_in, in, in_b, hipMemcpyHostToDevice)) != hipSuccess) {
         rc = fail((int)e, "unit buffers: %s", hipGetErrorString(e));
     } else {
+        (void)hipGetLastError();
         hipLaunchKernelGGL(rtw::unit_kernel<T>, dim3((count + 63) / 64), dim3(64), lds_bytes, 0, op, count, d_in, d_out, S, CS, C);
         if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost)) != hipSuccess)
             rc = fail((int)e, "unit kernel: %s", hipGetErrorString(e));
     }
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
+    if (d_in) HIP_IGNORE(hipFree(d_in));
+    if (d_out) HIP_IGNORE(hipFree(d_out));
     return rc;
 }
 
@@ -728,9 +760,9 @@ int rtw_scene_upload_f64(const rtw_scene_f64 *s, int device, rtw_scene_handle *o
 int rtw_scene_free(rtw_scene_handle h) {
     if (!h) return 0;
     DeviceGuard guard;
-    (void)hipSetDevice(h->device);
+    HIP_IGNORE(hipSetDevice(h->device));
     void *ptrs[] = {h->geom, h->mat0, h->mat1, h->scan, h->c_bound, h->c_exact, h->c_mat0, h->c_mat1, h->c_orig};
-    for (void *q : ptrs) if (q) (void)hipFree(q);
+    for (void *q : ptrs) if (q) HIP_IGNORE(hipFree(q));
     delete h;
     return 0;
 }
@@ -775,7 +807,7 @@ int rtw_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_generation.fetch_add(1);                 // every thread's "last render" is now stale (rtw_stats reports -6)
     for (auto &c : g_ctx) {
-        (void)hipSetDevice(c->device);
+        HIP_IGNORE(hipSetDevice(c->device));
         std::lock_guard<std::mutex> lk2(c->mu);
         c->recs.clear();
     }
