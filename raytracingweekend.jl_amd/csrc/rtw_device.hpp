@@ -479,6 +479,11 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
         clk.lap(4);
     }
     resolve_candidates<T, STRIDE>(src, o, d, tmin, closest, idx, list, cnt);
+#ifdef RTW_DUP_RESOLVE   // instruction-count probe: the final resolve twice (idempotent: same winner)
+    { T c2 = tmax; int i2 = -1; __asm__ volatile("" : "+v"(c2), "+v"(i2));
+      resolve_candidates<T, STRIDE>(src, o, d, tmin, c2, i2, list, cnt);
+      __asm__ volatile("" :: "v"(c2), "v"(i2)); }
+#endif
     clk.lap(5);
     t_hit = closest;
     return idx;

@@ -403,6 +403,11 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
         T len2 = 0;
         {
             bool pending = ball || new_sample;
+#ifdef RTW_DUP_REJECT    // instruction-count probe: the rejection loop twice (the first run on a copy of the generator)
+            { Rng r2 = rng; V3<T> q2 = {0, 0, 0}; T l2 = 0; bool p2 = pending;
+              while (__any(p2)) { if (p2) { l2 = reject_trial<T>(r2, ball, q2); p2 = !(l2 <= T(1)); } }
+              __asm__ volatile("" :: "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(l2), "v"((unsigned)r2.x), "v"((unsigned)r2.y)); }
+#endif
             while (__any(pending)) {
                 if (pending) {
                     len2 = reject_trial<T>(rng, ball, rp);
