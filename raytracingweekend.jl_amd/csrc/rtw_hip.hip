@@ -630,9 +630,11 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
     std::vector<int> devs;
     if (p->n_devices == -1) {
         int n = 0;
-        HIP_TRY(hipGetDeviceCount(&n));
+        const hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0)
+            return fail(e != hipSuccess ? (int)e : -21, "no HIP device available (%s); librtw_hip has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
         for (int d = 0; d < n; ++d) devs.push_back(d);
-        if (devs.empty()) return fail(-21, "no HIP device available; librtw_hip has no CPU fallback");
     } else if (p->n_devices > 1) {
         if (!p->device_ids) return fail(-1, "n_devices = %d but device_ids is null", p->n_devices);
         devs.assign(p->device_ids, p->device_ids + p->n_devices);

@@ -165,3 +165,21 @@ def test_check_julia_kat_detects_a_wrong_assumption(tmp_path):
     assert r.returncode == 1 and "rand(rng, Float32): low 23 bits" in r.stdout
     line = next(x for x in r.stdout.splitlines() if x.startswith("rand(rng, Float32)"))
     assert "FAIL" in line and r.stdout.count("FAIL") == 2        # that item and the summary line
+
+
+def test_c_host_example_compiles_and_links(tmp_path):
+    """include/rtw_hip.h is plain C99 and examples/render_c.c links against the built library (no GPU needed for that)"""
+    import subprocess
+    from rtw_amd import _capi
+    lib_dir = os.path.dirname(_capi.LIB_PATH)
+    if not os.path.exists(_capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    exe = str(tmp_path / "render_c")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "render_c.c"), "-L", lib_dir, "-lrtw_hip", f"-Wl,-rpath,{lib_dir}", "-lm", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    if not _has_gpu():                      # without a device it must fail loudly, not produce pixels
+        r = subprocess.run([exe, "64", "1"], capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 1 and "no HIP device" in r.stderr and not (tmp_path / "render_c.ppm").exists()
