@@ -175,6 +175,24 @@ def test_gather_mode_assembles_the_frame(rtw):
     dr.close()
 
 
+def test_c_host_example_renders_the_same_image(rtw, tmp_path):
+    """examples/render_c.c (plain C99 over include/rtw_hip.h, n_devices = -1) against the Python mirror"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from rtw_amd import _capi
+    lib_dir = os.path.dirname(_capi.LIB_PATH)
+    exe = str(tmp_path / "render_c")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "render_c.c"),
+                           "-L", lib_dir, "-lrtw_hip", f"-Wl,-rpath,{lib_dir}", "-lm", "-o", exe])
+    r = subprocess.run([exe, "96", "8"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and "samples" in r.stderr, r.stderr
+    got = rtw.imageio.load_ppm(str(tmp_path / "render_c.ppm"))
+    T = np.float32
+    img = rtw.render(rtw.scene_2_spheres(elem_type=T), rtw.t_default_cam(elem_type=T), 96, 8, depth=16, seed=1)
+    assert np.array_equal(got, rtw.imageio.to_u8(img))
+
+
 def test_stats_after_shutdown_reports_no_render(rtw):
     from rtw_amd import _capi
     L = _capi.lib()
