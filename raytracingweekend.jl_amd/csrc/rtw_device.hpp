@@ -350,18 +350,23 @@ template <typename T, int STRIDE, typename SRC>
 __device__ __forceinline__ void resolve_candidates(SRC src, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
                                                    const unsigned short *list, int cnt) {
     using V4 = typename Vec4<T>::type;
-    int i_next = cnt > 0 ? (int)list[0] : 0;
-    V4 s_next = src[i_next];
-    for (int c = 0; __any(c < cnt); ++c) {
-        const int i = i_next;
-        const V4 s = s_next;
-        i_next = (c + 1 < cnt) ? (int)list[(c + 1) * STRIDE] : 0;
-        s_next = src[i_next];
+    auto test = [&](int c, int i, const V4 &s) {
         if (c < cnt) {
             T hb, disc, root;
             sphere_disc<T>(s.x, s.y, s.z, s.w, o, d, hb, disc);
             if (sphere_root<T>(hb, disc, tmin, closest, root)) { closest = root; idx = i; }
         }
+    };
+    // two entries per trip, fetched one ahead, in two fixed register sets (no copies between trips)
+    int ia = cnt > 0 ? (int)list[0] : 0;
+    V4 sa = src[ia];
+    for (int c = 0; __any(c < cnt); c += 2) {
+        const int ib = (c + 1 < cnt) ? (int)list[(c + 1) * STRIDE] : 0;
+        const V4 sb = src[ib];
+        test(c, ia, sa);
+        ia = (c + 2 < cnt) ? (int)list[(c + 2) * STRIDE] : 0;
+        sa = src[ia];
+        if (__any(c + 1 < cnt)) test(c + 1, ib, sb);
     }
 }
 
@@ -463,8 +468,10 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
             cnt += 1;
             m &= ~(0x80000000u >> b);
         };
-        if (!__any(cnt + (int)__popc(m) > RTW_LIST_CAP)) {
-            while (__any(m != 0u)) { if (m != 0u) push_first(); }          // the common case: a tight loop
+        if (!__any(m != 0u)) {
+            // no lane has a candidate among these 32 spheres
+        } else if (!__any(cnt + (int)__popc(m) > RTW_LIST_CAP)) {
+            do { if (m != 0u) push_first(); } while (__any(m != 0u));     // the common case: a tight loop
         } else {
             while (__any(m != 0u)) {
                 if (__any(cnt >= RTW_LIST_CAP)) {     // some lane's list is full: resolve all lists now
