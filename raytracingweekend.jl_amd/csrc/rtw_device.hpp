@@ -43,13 +43,19 @@ template <typename T> __device__ __forceinline__ bool near_zero(V3<T> a) { retur
 // ---- RNG: per-lane Xoroshiro128+ (src/init.jl:2-12, src/rand.jl:5-13; RandomNumbers.jl) -----
 struct Rng { uint64_t x, y; };
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
+// Xoroshiro128+ (55/14/36), one step:  out = x + y;  s1 = x ^ y;  x' = rotl(x, 55) ^ s1 ^ (s1 << 14);  y' = rotl(s1, 36).
+// Written on 32-bit halves: the rotations and the long shift are funnel shifts (v_alignbit_b32) and each half of x' is
+// one three-input xor (v_bitop3_b32) -- 10 VALU instructions + the output add instead of the 14 the compiler makes of the
+// 64-bit form.  (hi:lo) >> s, low word:
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
 __device__ __forceinline__ uint64_t rng_next(Rng &r) {
-    uint64_t x = r.x, y = r.y;
-    uint64_t out = x + y;
-    uint64_t s1 = x ^ y;
-    r.x = rotl64(x, 55) ^ s1 ^ (s1 << 14);
-    r.y = rotl64(s1, 36);
+    const uint32_t xl = (uint32_t)r.x, xh = (uint32_t)(r.x >> 32), yl = (uint32_t)r.y, yh = (uint32_t)(r.y >> 32);
+    const uint64_t out = r.x + r.y;                               // (callers that keep 23 bits get a 32-bit add)
+    const uint32_t sl = xl ^ yl, sh = xh ^ yh;
+    const uint32_t nxl = __builtin_amdgcn_bitop3_b32(funnel(xh, xl, 9), sl, sl << 14, 0x96);              // rotl 55 = rotr 9
+    const uint32_t nxh = __builtin_amdgcn_bitop3_b32(funnel(xl, xh, 9), sh, funnel(sh, sl, 18), 0x96);
+    r.x = ((uint64_t)nxh << 32) | nxl;
+    r.y = ((uint64_t)funnel(sl, sh, 28) << 32) | funnel(sh, sl, 28);                                    // rotl 36 = swap halves, rotl 4
     return out;
 }
 __device__ __forceinline__ uint64_t splitmix64(uint64_t &s) {

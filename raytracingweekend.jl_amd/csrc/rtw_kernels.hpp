@@ -408,11 +408,9 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
               while (__any(p2)) { if (p2) { l2 = reject_trial<T>(r2, ball, q2); p2 = !(l2 <= T(1)); } }
               __asm__ volatile("" :: "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(l2), "v"((unsigned)r2.x), "v"((unsigned)r2.y)); }
 #endif
-            while (__any(pending)) {
-                if (pending) {
-                    len2 = reject_trial<T>(rng, ball, rp);
-                    pending = !(len2 <= T(1));
-                }
+            while (pending) {
+                len2 = reject_trial<T>(rng, ball, rp);
+                pending = !(len2 <= T(1));
             }
         }
         // ---- (F) finish the scatter / the camera ray; ONE normalize for all of them ----
