@@ -313,6 +313,12 @@ __device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned l
 // with spheres that can never be hit (r*r = -1e30 => discriminant < 0 always).
 #define RTW_SPHERE_WORD 32
 #define RTW_SPHERE_TAIL 8
+// entries of the geom / mat arrays: the padded scan groups + one prefetch group, and at least whole blocks of 32
+// (hit_world_mfma can list the padding spheres of its last block for a ray that takes every sphere)
+__host__ __device__ inline int scene_geom_alloc(int n, int n_pad) {
+    const int a = n_pad + RTW_SPHERE_TAIL, b = ((n + 31) / 32) * 32;
+    return a > b ? a : b;
+}
 template <typename T> struct DevScene {
     const float *scan;   // what pass 1 streams through scalar loads (binary32 for BOTH precisions):
                          //   Float32: geom itself, 4 floats per sphere (cx, cy, cz, r^2) -- the exact contract discriminant;
@@ -322,6 +328,15 @@ template <typename T> struct DevScene {
     const typename Vec4<T>::type *mat0;
     const typename Vec4<T>::type *mat1;
     int n, n_pad;   // n_pad: multiple of ScanGroup<T>::N (the tail group lies beyond n_pad)
+    // pass 1 on the matrix pipe (hit_world_mfma): per block of 32 spheres two A operands of v_mfma_f32_32x32x16_f16
+    // (64 lanes x 16 B each: [P1][P2]), one more block of padding for the prefetch; see the derivation there
+    const uint4 *mf_ops;
+    int mf_blocks;          // ceil(n / 32)
+    float mf_sc;            // power of two: lengths are scaled by it before they are split into f16 pieces
+    float mf_sigma2;        // mf_sc^2
+    float mf_oo_keep;       // 1 - (the ray's share of the relative margin)
+    float mf_o1_coef;       // absolute margin per unit of |o|_1
+    float mf_o_max;         // rays with a larger |o_k| (or non-unit, non-finite ones) take every sphere as a candidate
 };
 
 // Candidate lists: pass 1 of the scan appends the indices of the spheres whose discriminant is
@@ -499,6 +514,195 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 #endif
     clk.lap(5);
     t_hit = closest;
+    return idx;
+}
+
+// ==== pass 1 on the matrix pipe ====================================================================================
+// The discriminant of src/hit.jl:13-18 is BILINEAR in (ray features) x (sphere features):
+//     -hb = [dx dy dz -o.d] . [cx cy cz 1]                       (P1)
+//      m  = [2ox 2oy 2oz 1] . [cx cy cz r^2 - |c|^2]  - |o|^2      (P2 - oo)
+//      D  = hb^2 + m
+// so one v_mfma_f32_32x32x16_f16 per product evaluates 32 spheres x 32 rays, and the VALU is left with fma + sub +
+// v_alignbit per (ray, sphere) instead of the 11 instructions of hit_world's pass 1 (f32-input MFMAs run on the FP32 vector
+// lanes themselves and gain nothing; tools/ubench_mfma_overlap.hip).  Precision: every f32 feature x is split into two f16
+// pieces x = p1 + p2 (+- 2^-22 |x|; f16 subnormals are honoured by the instruction, tools/ubench_mfma_f16_numerics.hip) and
+// the K = 16 slots of the instruction hold the 4 features x 4 cross terms (a1 b1, a1 b2, a2 b1, a2 b2), so the products are
+// exact in the f32 accumulator and the measured accumulation error is <= 2^-21.8 x max|term| (the bound below assumes
+// 2^-20 x sum|terms|).  The result is only a FILTER, like the binary32 filter of hit_world<double>: pass 2 applies the exact
+// contract test to every candidate, so pass 1 must flag a SUPERSET of {contract discriminant >= 0}.  With lengths scaled
+// by the power of two s (mf_sc: |c_k| s <= 2^11), u = 2^-24, eta = 2^-22, beta = 2^-20 and |d|^2 <= 1.001:
+//     |HB_comp - HB|  <= 1.001 (2 eta + beta + 3.01 u) (|c| + |o|) + floors           (split of d, c, o.d; o.d in f32; MFMA)
+//     |M_comp  - M |  <= 2.002 (2 eta + beta) |o||c| + (eta + beta) |k'| + 4.02 u |o|^2 + floors,   k' = r^2 - |c|^2 + Gs
+//     roundings of fma / sub <= 3 u (HB^2 + |M| + |o|^2),   contract vs exact arithmetic <= 20 u (|o - c| + r)^2
+// which sum to  E <= A_S (|o| + |c|)^2 + A_r (r^2 + |c|^2) + floors  with  A_S = 29 x 2^-22,  A_r = 15.5 x 2^-22  (inputs
+// rounded from binary64 add 1.5 x 2^-22: inside the constants used).  The upload stores  k' = r^2 - |c|^2 + Gs  with
+// Gs = 1.02 [(2 A_S' + A_r') |c|^2 + A_r' r^2 + ...],  A_S' = 2^-17, A_r' = 2^-18, and the ray subtracts
+// oo' = |o|^2 (1 - 2.05 x 2^-16) - (floor coefficient) |o|_1, so that  D >= -E_contract  =>  W > 0: sign bit clear.
+// Rays that are not (nearly) unit, not finite or far outside the scene take every sphere as a candidate; lanes without a
+// ray take none.  Lane layout of the instruction (A: row l & 31, k = 8 (l >> 5) + e; C/D: col l & 31, row (reg & 3) +
+// 8 (reg >> 2) + 4 (l >> 5)): lanes l and l + 32 hold the SAME 32 rays of a half wave and different spheres, so the
+// candidates go to a wave-shared list of (owner lane, sphere) pairs in LDS, and pass 2 walks that list 64 pairs at a
+// time whatever the owner (no lane waits for the longest per-lane list any more).  Pass 2 is order-free: the reference's
+// scan returns the minimum over the spheres of their first root in [tmin, inf) and the LAST sphere among exact ties,
+// which is the minimum of the 64-bit keys (root bits, ~sphere) -- an LDS atomic min per candidate (Float64: min on the
+// root, then max on the index among the candidates that equal it).
+#define RTW_PAIR_CAP 512     // (owner, sphere) pairs per wave; a full list is resolved early
+typedef _Float16 rtw_h8 __attribute__((ext_vector_type(8)));
+typedef float rtw_f16v __attribute__((ext_vector_type(16)));
+
+struct WaveScratch {
+    unsigned *pairs;              // RTW_PAIR_CAP entries: owner lane << 16 | sphere
+    unsigned long long *keys;     // 64 entries: Float32 (root bits << 32 | ~sphere); Float64 root bits
+    unsigned *kidx;               // Float64 only: 64 entries, sphere + 1
+};
+
+// x = p1 + p2 with p1 = RN16(x), p2 = RN16(x - p1); returns p1 | p2 << 16
+__device__ __forceinline__ unsigned split_f16(float x) {
+    const _Float16 p1 = (_Float16)x;
+    const _Float16 p2 = (_Float16)(x - (float)p1);
+    return (unsigned)__builtin_bit_cast(unsigned short, p1) | ((unsigned)__builtin_bit_cast(unsigned short, p2) << 16);
+}
+__device__ __forceinline__ float lane_get(float v, unsigned src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
+}
+__device__ __forceinline__ double lane_get(double v, unsigned src_lane) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(unsigned)((unsigned long long)b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Walk n pairs of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
+template <typename T, typename SRC>
+__device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane) {
+    using V4 = typename Vec4<T>::type;
+    __builtin_amdgcn_wave_barrier();
+    for (unsigned p0 = 0; p0 < n; p0 += 64u) {
+        const unsigned p = p0 + lane;
+        const bool valid = p < n;
+        const unsigned e = ws.pairs[valid ? p : 0u];
+        const unsigned owner = e >> 16, sph = e & 0xffffu;
+        const V3<T> po = {lane_get(o.x, owner), lane_get(o.y, owner), lane_get(o.z, owner)};
+        const V3<T> pd = {lane_get(d.x, owner), lane_get(d.y, owner), lane_get(d.z, owner)};
+        const V4 s = src[sph];
+        T hb, disc, root = 0;
+        sphere_disc<T>(s.x, s.y, s.z, s.w, po, pd, hb, disc);
+        const bool hit = valid && sphere_root<T>(hb, disc, tmin, (T)__builtin_huge_val(), root);
+        if constexpr (sizeof(T) == 4) {
+            if (hit) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(root) << 32) | (unsigned long long)(0xffffffffu - sph);
+                __hip_atomic_fetch_min(&ws.keys[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            const unsigned long long tb = (unsigned long long)__double_as_longlong(root);
+            unsigned long long old = 0ull;
+            if (hit) old = __hip_atomic_fetch_min(&ws.keys[owner], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long cur = ws.keys[owner];
+            if (hit && tb == cur && old > tb) ws.kidx[owner] = 0u;              // the candidate that lowered the minimum to its final value of this step
+            __builtin_amdgcn_wave_barrier();
+            if (hit && tb == cur) __hip_atomic_fetch_max(&ws.kidx[owner], sph + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Closest hit for the rays of a whole wave (every lane calls it, convergently; has_ray = this lane has a ray).
+template <typename T, typename SRC, typename CLK = NoClock>
+__device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<T> o, V3<T> d, bool has_ray, T tmin, T &t_hit,
+                                              const WaveScratch &ws, unsigned lane, CLK &&clk = NoClock()) {
+    const unsigned H = lane >> 5;
+    // ---- ray features (binary32) ----
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const float s2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    const float oinf = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz));
+    const bool ok = has_ray && s2 <= 1.0009f && oinf <= w.mf_o_max;                  // (false for NaN)
+    const float od = __builtin_fmaf(oz, dz, __builtin_fmaf(oy, dy, ox * dx));
+    const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float o1 = (__builtin_fabsf(ox) + __builtin_fabsf(oy)) + __builtin_fabsf(oz);
+    float too = w.mf_sigma2 * __builtin_fmaf(oo, w.mf_oo_keep, -(w.mf_o1_coef * o1));
+    if (!ok) too = has_ray ? -__builtin_huge_valf() : __builtin_huge_valf();        // every sphere / no sphere
+    const float z = ok ? 1.0f : 0.0f;
+    const float f1[4] = {dx * z, dy * z, dz * z, -(od * w.mf_sc) * z};
+    const float f2[4] = {(ox + ox) * w.mf_sc * z, (oy + oy) * w.mf_sc * z, (oz + oz) * w.mf_sc * z, 32768.0f * z};
+    // Lane (H, j) supplies features 2H and 2H + 1 of ray j (first half wave: h = 0) / ray 32 + j (h = 1)
+    auto half_features = [&](const float (&f)[4], unsigned (&wa)[2], unsigned (&wb)[2]) {
+        const unsigned other = lane ^ 32u;
+        const float g0 = lane_get(f[0], other), g1 = lane_get(f[1], other), g2 = lane_get(f[2], other), g3 = lane_get(f[3], other);
+        // h = 0: lanes < 32 own (f0, f1); lanes >= 32 take (f2, f3) of lane - 32.  h = 1: lanes < 32 take (f0, f1) of lane + 32; lanes >= 32 own (f2, f3)
+        wa[0] = split_f16(H ? g2 : f[0]); wb[0] = split_f16(H ? g3 : f[1]);
+        wa[1] = split_f16(H ? f[2] : g0); wb[1] = split_f16(H ? f[3] : g1);
+    };
+    unsigned a1[2], b1[2], a2[2], b2[2];
+    half_features(f1, a1, b1);
+    half_features(f2, a2, b2);
+    const float too_other = lane_get(too, lane ^ 32u);
+    const float too_h[2] = {H ? too_other : too, H ? too : too_other};
+    rtw_h8 B1[2], B2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint4 q1 = {a1[h], a1[h], b1[h], b1[h]}, q2 = {a2[h], a2[h], b2[h], b2[h]};
+        B1[h] = __builtin_bit_cast(rtw_h8, q1);
+        B2[h] = __builtin_bit_cast(rtw_h8, q2);
+    }
+    // ---- the result cells ----
+    if constexpr (sizeof(T) == 4) ws.keys[lane] = ~0ull;
+    else { ws.keys[lane] = ~0ull; ws.kidx[lane] = 0u; }
+
+    const unsigned lane_const = ((lane & 31u) << 16) + 16u * H;
+    unsigned total = 0;                                   // wave-uniform
+    const uint4 *pa = w.mf_ops + lane;
+    uint4 A1 = pa[0], A2 = pa[64];
+    for (int blk = 0; blk < w.mf_blocks; ++blk) {
+        const uint4 N1 = pa[(blk + 1) * 128], N2 = pa[(blk + 1) * 128 + 64];      // (one block of padding)
+        unsigned mask = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const rtw_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const rtw_f16v P1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[h], zero, 0, 0, 0);
+            const rtw_f16v P2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[h], zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float W = __builtin_fmaf(P1[r], P1[r], P2[r]) - too_h[h];
+                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(W), 31);
+            }
+        }
+        clk.lap(2);
+        unsigned m = ~mask;                               // bit 31 - b: half wave b >> 4, result register b & 15
+        const unsigned ebase = lane_const + (unsigned)blk * 32u;
+        for (;;) {
+            const unsigned long long act = __ballot(m != 0u);
+            if (!act) break;
+            if (total + 64u > RTW_PAIR_CAP) {
+                clk.lap(4);
+                resolve_pairs<T>(src, o, d, tmin, ws, total, lane);
+                total = 0;
+                clk.lap(5);
+            }
+            if (m != 0u) {
+                const unsigned b = (unsigned)__clz((int)m);
+                m &= ~(0x80000000u >> b);
+                const unsigned pos = total + __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+                ws.pairs[pos] = ebase + ((b & 16u) << 17) + (b & 15u);
+            }
+            total += (unsigned)__popcll(act);
+        }
+        clk.lap(4);
+        A1 = N1; A2 = N2;
+    }
+    resolve_pairs<T>(src, o, d, tmin, ws, total, lane);
+    clk.lap(5);
+    int idx;
+    if constexpr (sizeof(T) == 4) {
+        const unsigned long long k = ws.keys[lane];
+        idx = k == ~0ull ? -1 : (int)(0xffffffffu - (unsigned)k);
+        t_hit = __uint_as_float((unsigned)(k >> 32));
+    } else {
+        const unsigned long long k = ws.keys[lane];
+        idx = (int)ws.kidx[lane] - 1;
+        t_hit = __longlong_as_double((long long)k);
+    }
+    if (!has_ray) idx = -1;
     return idx;
 }
 
@@ -701,7 +905,7 @@ __device__ __forceinline__ void stage_cull_scene(const CullScene<T> &w, typename
 // Stage the scene's geom array into LDS (all threads of the block; caller synchronises).
 template <typename T>
 __device__ __forceinline__ void stage_scene(const DevScene<T> &w, typename Vec4<T>::type *dst) {
-    const int n_alloc = w.n_pad + RTW_SPHERE_TAIL;
+    const int n_alloc = scene_geom_alloc(w.n, w.n_pad);
     for (int i = threadIdx.x; i < n_alloc; i += blockDim.x) dst[i] = w.geom[i];
 }
 

@@ -176,6 +176,10 @@ struct rtw_scene_dev {
     int n, n_pad;
     void *geom, *mat0, *mat1;
     void *scan;      // Float64: the binary32 filter array of pass 1 (8 floats per sphere); Float32: null (geom itself)
+    // pass 1 on the matrix pipe (hit_world_mfma): A operands per block of 32 spheres, scales and the ray's share of the margin
+    void *mf_ops;    // null: the scene's extent is outside what the f16 split covers (the VALU scan is used)
+    int mf_blocks;
+    float mf_sc, mf_sigma2, mf_oo_keep, mf_o1_coef, mf_o_max;
     // opt-in group-cull mode (RTW_FLAG_GROUP_CULL): cluster-major copies
     void *c_bound, *c_exact, *c_mat0, *c_mat1;
     unsigned short *c_orig;
@@ -299,6 +303,72 @@ rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
     return C;
 }
 
+// Operands of pass 1 on the matrix pipe (rtw_device.hpp, hit_world_mfma): per block of 32 spheres two A operands of
+// v_mfma_f32_32x32x16_f16, P1 = [cx cy cz 1] s and P2 = [cx cy cz k'] (k' = r^2 - |c|^2 + the sphere's share Gs of the
+// error margin), every feature split into two f16 pieces.  Row i of the instruction holds sphere 16 ((i >> 2) & 1) +
+// (((i >> 3) << 2) | (i & 3)) of the block, so that result register r of lane (H, j) is sphere 16 H + r.
+template <typename T, typename V4>
+int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h) {
+    h->mf_ops = nullptr; h->mf_blocks = 0;
+    if (n <= 0) return 0;
+    double emax = 0;
+    for (int i = 0; i < n; ++i) {
+        const double r = std::sqrt(std::fabs((double)geom[i].w));
+        emax = std::max(emax, std::max(std::max(std::fabs((double)(float)geom[i].x), std::fabs((double)(float)geom[i].y)),
+                                       std::max(std::fabs((double)(float)geom[i].z), r)));
+    }
+    if (!(emax > 0) || !std::isfinite(emax)) return 0;
+    int ex = 0;
+    (void)std::frexp(emax, &ex);                         // emax <= 2^ex
+    if (ex > 40 || ex < -40) return 0;                   // outside what the scaled f16 pieces cover: VALU scan
+    const double sc = std::ldexp(1.0, 11 - ex), sig2 = sc * sc;
+    const double phi_c = std::ldexp(1.0, -25) / sc, phi_k = std::ldexp(1.0, -10) / sig2;
+    const double A_S = std::ldexp(1.0, -17), A_r = std::ldexp(12.0, -22);
+    auto split = [](float x, unsigned &w0, unsigned &w1) {
+        const _Float16 p1 = (_Float16)x;
+        const _Float16 p2 = (_Float16)(x - (float)p1);
+        unsigned short b1, b2;
+        memcpy(&b1, &p1, 2); memcpy(&b2, &p2, 2);
+        w0 = (unsigned)b1 | ((unsigned)b1 << 16);         // (a1, a1)
+        w1 = (unsigned)b2 | ((unsigned)b2 << 16);         // (a2, a2)
+    };
+    const int nb = (n + 31) / 32;
+    std::vector<uint4> ops((size_t)(nb + 1) * 128);
+    for (int blk = 0; blk <= nb; ++blk)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31, H = lane >> 5;
+            const int sph = blk * 32 + 16 * ((i >> 2) & 1) + (((i >> 3) << 2) | (i & 3));
+            float f1[4] = {0, 0, 0, 0}, f2[4] = {0, 0, 0, -32768.0f};         // padding sphere: W = -2^30 - oo' < 0
+            if (sph < n) {
+                const double cx = (double)(float)geom[sph].x, cy = (double)(float)geom[sph].y, cz = (double)(float)geom[sph].z;
+                const double r2 = (double)geom[sph].w, c2 = cx * cx + cy * cy + cz * cz;
+                const double Gs = 1.02 * ((2 * A_S + A_r) * c2 + A_r * r2 + 9 * phi_c * (std::fabs(cx) + std::fabs(cy) + std::fabs(cz)) + phi_k);
+                double kx = (r2 - c2 + Gs) * sig2 / 32768.0;
+                float kf = (float)kx;
+                if ((double)kf < kx) kf = std::nextafter(kf, INFINITY);
+                f1[0] = f2[0] = (float)(cx * sc); f1[1] = f2[1] = (float)(cy * sc); f1[2] = f2[2] = (float)(cz * sc);
+                f1[3] = 1.0f; f2[3] = kf;
+            }
+            uint4 q1, q2;
+            split(f1[2 * H], q1.x, q1.y); split(f1[2 * H + 1], q1.z, q1.w);
+            split(f2[2 * H], q2.x, q2.y); split(f2[2 * H + 1], q2.z, q2.w);
+            ops[(size_t)blk * 128 + lane] = q1;
+            ops[(size_t)blk * 128 + 64 + lane] = q2;
+        }
+    HIP_TRY(hipMalloc(&h->mf_ops, ops.size() * sizeof(uint4)));
+    HIP_TRY(hipMemcpy(h->mf_ops, ops.data(), ops.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    h->mf_blocks = nb;
+    h->mf_sc = (float)sc; h->mf_sigma2 = (float)sig2;
+    float keep = (float)(1.0 - 1.02 * 2 * A_S);
+    if ((double)keep > 1.0 - 1.02 * 2 * A_S) keep = std::nextafter(keep, 0.0f);
+    h->mf_oo_keep = keep;
+    float coef = (float)(1.02 * 9 * phi_c);
+    if ((double)coef < 1.02 * 9 * phi_c) coef = std::nextafter(coef, INFINITY);
+    h->mf_o1_coef = coef;
+    h->mf_o_max = (float)(std::ldexp(1.0, 14) / sc);
+    return 0;
+}
+
 template <typename T, typename SceneT>
 int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     if (!s || !out) return fail(-1, "null argument");
@@ -321,7 +391,7 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     const int n = s->n;
     constexpr int grp = rtw::ScanGroup<T>::N;                                            // 8 (f32) / 4 (f64)
     const int n_pad = ((n + grp - 1) / grp) * grp;                                       // 0 spheres: no scan at all
-    const int n_alloc = n_pad + RTW_SPHERE_TAIL;                                          // prefetch tail group
+    const int n_alloc = rtw::scene_geom_alloc(n, n_pad);                                  // prefetch tail group / whole blocks of 32
     if (n_pad >= 65536) return fail(-5, "too many spheres (%d): candidate lists hold 16-bit indices", n);
     std::vector<V4> geom(n_alloc), mat0(n_alloc), mat1(n_alloc);
     for (int i = 0; i < n_alloc; ++i) {
@@ -365,9 +435,23 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
         HIP_TRY(hipMalloc(&h->scan, f.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->scan, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    if (int rc = build_mfma_operands<T>(geom, n, h.get())) return rc;
     if (int rc = build_cull<T>(s, h.get())) return rc;
     *out = h.release();
     return 0;
+}
+
+template <typename T>
+rtw::DevScene<T> dev_scene_of(const rtw_scene_dev *h) {
+    using V4 = typename rtw::Vec4<T>::type;
+    rtw::DevScene<T> S;
+    memset(&S, 0, sizeof S);
+    S.geom = (const V4 *)h->geom; S.mat0 = (const V4 *)h->mat0; S.mat1 = (const V4 *)h->mat1;
+    S.scan = (const float *)(h->scan ? h->scan : h->geom);
+    S.n = h->n; S.n_pad = h->n_pad;
+    S.mf_ops = (const uint4 *)h->mf_ops; S.mf_blocks = h->mf_blocks;
+    S.mf_sc = h->mf_sc; S.mf_sigma2 = h->mf_sigma2; S.mf_oo_keep = h->mf_oo_keep; S.mf_o1_coef = h->mf_o1_coef; S.mf_o_max = h->mf_o_max;
+    return S;
 }
 
 // magic number for exact unsigned 32-bit division by an invariant d >= 1 (Granlund-Montgomery / Hacker's
@@ -435,11 +519,8 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
         C.u[k] = cam->u[k]; C.v[k] = cam->v[k]; C.w[k] = cam->w[k];
     }
     C.lens_radius = cam->lens_radius;
-    rtw::DevScene<T> S;
     using V4 = typename rtw::Vec4<T>::type;
-    S.geom = (const V4 *)scene->geom; S.mat0 = (const V4 *)scene->mat0; S.mat1 = (const V4 *)scene->mat1;
-    S.scan = (const float *)(scene->scan ? scene->scan : scene->geom);
-    S.n = scene->n; S.n_pad = scene->n_pad;
+    const rtw::DevScene<T> S = dev_scene_of<T>(scene);
 
     // persistent grid: enough 256-thread blocks to fill every CU at the kernel's occupancy
     static const bool phase_profile = getenv("RTW_PHASE_PROFILE") != nullptr;   // debugging aid, not for timed runs
@@ -449,13 +530,18 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     const rtw::CullScene<T> CS = cull_scene_of<T>(scene);
     const size_t n_cull = (size_t)rtw::cull_exact_count(CS);
     const size_t geom_bytes = cull ? n_cull * sizeof(V4) + ((n_cull * sizeof(unsigned short) + 15) / 16) * 16
-                                   : (size_t)(scene->n_pad + RTW_SPHERE_TAIL) * sizeof(V4);
+                                   : (size_t)rtw::scene_geom_alloc(scene->n, scene->n_pad) * sizeof(V4);
     const bool lds_scene = geom_bytes <= RTW_LDS_SCENE_MAX_BYTES;
-    const size_t lds_bytes = list_bytes + shared_bytes + (lds_scene ? geom_bytes : 0);
+    // the plain scan runs pass 1 on the matrix pipe (RTW_SCAN=valu: the all-VALU scan, for A/B measurements)
+    static const bool force_valu = getenv("RTW_SCAN") != nullptr && strcmp(getenv("RTW_SCAN"), "valu") == 0;
+    const bool mfma = !cull && scene->mf_ops != nullptr && !force_valu;
+    const size_t lds_bytes = list_bytes + shared_bytes + (mfma ? rtw::mfma_cell_bytes<T>() : 0) + (lds_scene ? geom_bytes : 0);
     typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, rtw::CullScene<T>, T *, rtw::DevCounters *);
     kern_t kern;
     if (cull && phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true>;
     else if (cull) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true>;
+    else if (mfma && phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, false, true> : (kern_t)rtw::trace_kernel<T, true, false, false, true>;
+    else if (mfma) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false, true> : (kern_t)rtw::trace_kernel<T, false, false, false, true>;
     else if (phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, false> : (kern_t)rtw::trace_kernel<T, true, false, false>;
     else kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false> : (kern_t)rtw::trace_kernel<T, false, false, false>;
     int blocks_per_cu = 0;
@@ -681,7 +767,7 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
     if (op < 0 || op >= rtw::U_NUM_OPS) return fail(-2, "unknown unit op %d", op);
     if (count < 0 || (count > 0 && (!in || !out))) return fail(-1, "null argument");
     if (count == 0) return 0;
-    const bool needs_scene = op == rtw::U_HIT_WORLD || op == rtw::U_RAY_COLOR || op == rtw::U_HIT_WORLD_LDS || op == rtw::U_HIT_WORLD_CULL;
+    const bool needs_scene = op == rtw::U_HIT_WORLD || op == rtw::U_RAY_COLOR || op == rtw::U_HIT_WORLD_LDS || op == rtw::U_HIT_WORLD_CULL || op == rtw::U_HIT_WORLD_MFMA;
     if (needs_scene && !scene) return fail(-1, "op %d needs a scene", op);
     if (op == rtw::U_GET_RAY && !cam) return fail(-1, "op %d needs a camera", op);
     DeviceGuard guard;
@@ -690,15 +776,13 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
     DeviceCtx *ctx;
     if (int rc = get_ctx(dev, &ctx)) return rc;
     rtw_scene_handle h_raw = nullptr;
-    rtw::DevScene<T> S{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    rtw::DevScene<T> S;
+    memset(&S, 0, sizeof S);
     rtw::CullScene<T> CS;
     memset(&CS, 0, sizeof CS);
     if (needs_scene) {
         if (int rc = upload_scene<T>(scene, dev, &h_raw)) return rc;
-        using V4 = typename rtw::Vec4<T>::type;
-        S.geom = (const V4 *)h_raw->geom; S.mat0 = (const V4 *)h_raw->mat0; S.mat1 = (const V4 *)h_raw->mat1;
-        S.scan = (const float *)(h_raw->scan ? h_raw->scan : h_raw->geom);
-        S.n = h_raw->n; S.n_pad = h_raw->n_pad;
+        S = dev_scene_of<T>(h_raw);
         CS = cull_scene_of<T>(h_raw);
     }
     ScenePtr h(h_raw);
@@ -715,7 +799,8 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
     }
     using V4 = typename rtw::Vec4<T>::type;
     size_t lds_bytes = 0;
-    if (op == rtw::U_HIT_WORLD_LDS) lds_bytes = (size_t)(S.n_pad + RTW_SPHERE_TAIL) * sizeof(V4);
+    if (op == rtw::U_HIT_WORLD_LDS || op == rtw::U_HIT_WORLD_MFMA) lds_bytes = (size_t)rtw::scene_geom_alloc(S.n, S.n_pad) * sizeof(V4);
+    if (op == rtw::U_HIT_WORLD_MFMA && !S.mf_ops) return fail(-5, "the scene has no matrix-pipe scan operands (unit op %d)", op);
     if (op == rtw::U_HIT_WORLD_CULL) {
         const size_t n_cull = (size_t)rtw::cull_exact_count(CS);
         lds_bytes = n_cull * sizeof(V4) + ((n_cull * sizeof(unsigned short) + 15) / 16) * 16;
@@ -763,7 +848,7 @@ int rtw_scene_free(rtw_scene_handle h) {
     if (!h) return 0;
     DeviceGuard guard;
     HIP_IGNORE(hipSetDevice(h->device));
-    void *ptrs[] = {h->geom, h->mat0, h->mat1, h->scan, h->c_bound, h->c_exact, h->c_mat0, h->c_mat1, h->c_orig};
+    void *ptrs[] = {h->geom, h->mat0, h->mat1, h->scan, h->mf_ops, h->c_bound, h->c_exact, h->c_mat0, h->c_mat1, h->c_orig};
     for (void *q : ptrs) if (q) HIP_IGNORE(hipFree(q));
     delete h;
     return 0;

@@ -117,9 +117,19 @@ template <> struct TraceWaves<double> { static constexpr int value = RTW_TRACE_W
 #ifndef RTW_TRACE_WAVES_CULL_F32
 #define RTW_TRACE_WAVES_CULL_F32 5
 #endif
-template <typename T, bool CULL> struct TraceWavesOf { static constexpr int value = TraceWaves<T>::value; };
-template <> struct TraceWavesOf<float, true> { static constexpr int value = RTW_TRACE_WAVES_CULL_F32; };
-template <> struct TraceWavesOf<double, true> { static constexpr int value = 3; };
+template <typename T, bool CULL, bool MFMA = false> struct TraceWavesOf { static constexpr int value = TraceWaves<T>::value; };
+template <> struct TraceWavesOf<float, true, false> { static constexpr int value = RTW_TRACE_WAVES_CULL_F32; };
+template <> struct TraceWavesOf<double, true, false> { static constexpr int value = 3; };
+#ifndef RTW_TRACE_WAVES_MFMA_F32
+#define RTW_TRACE_WAVES_MFMA_F32 5
+#endif
+#ifndef RTW_TRACE_WAVES_MFMA_F64
+#define RTW_TRACE_WAVES_MFMA_F64 4
+#endif
+template <> struct TraceWavesOf<float, false, true> { static constexpr int value = RTW_TRACE_WAVES_MFMA_F32; };   // 32 result registers per product
+template <> struct TraceWavesOf<double, false, true> { static constexpr int value = RTW_TRACE_WAVES_MFMA_F64; };
+// LDS of the matrix-pipe scan per workgroup (4 waves): the result cells (the pair lists take the place of the per-lane lists)
+template <typename T> __host__ __device__ constexpr size_t mfma_cell_bytes() { return 4 * (64 * sizeof(unsigned long long) + (sizeof(T) == 8 ? 64 * sizeof(unsigned) : 0)); }
 
 // store_job / open_job run once per job.  Inlined: as real calls (noinline) they keep the lane loop's register
 // pressure lower, but every call saves ~20 live VGPRs to scratch -- 2.7 GB of HBM writes per frame (PMC).
@@ -196,9 +206,10 @@ __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned la
     if (lane == 0) S->job = g;
 }
 
-template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL>
-__global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_kernel(KParams P_arg, Camera<T> cam_arg, DevScene<T> scene,
+template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL, bool MFMA = false>
+__global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void trace_kernel(KParams P_arg, Camera<T> cam_arg, DevScene<T> scene,
                                                    CullScene<T> cull, T *__restrict__ out, DevCounters *ctr) {
+    static_assert(!(CULL && MFMA), "the matrix-pipe scan is the plain scan");
     using V4 = typename Vec4<T>::type;
     const unsigned lane = lane_id();
     // LDS: [per-lane candidate lists, stride 256][job slots, ticket, camera][scene geom copy (LDS_SCENE only)]
@@ -207,7 +218,17 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
     constexpr size_t list_bytes = RTW_LIST_CAP * 256 * sizeof(unsigned short);
     constexpr size_t shared_bytes = (sizeof(WgShared<T>) + 15) / 16 * 16;
     WgShared<T> *sh = reinterpret_cast<WgShared<T> *>(smem + list_bytes);
-    V4 *lds_geom = reinterpret_cast<V4 *>(smem + list_bytes + shared_bytes);
+    constexpr size_t cell_bytes = MFMA ? mfma_cell_bytes<T>() : 0;
+    V4 *lds_geom = reinterpret_cast<V4 *>(smem + list_bytes + shared_bytes + cell_bytes);
+    WaveScratch ws = {nullptr, nullptr, nullptr};
+    if constexpr (MFMA) {
+        static_assert(list_bytes == 4 * RTW_PAIR_CAP * sizeof(unsigned), "the pair lists reuse the per-lane list area");
+        const unsigned wv = threadIdx.x >> 6;
+        unsigned char *cells = smem + list_bytes + shared_bytes;
+        ws.pairs = reinterpret_cast<unsigned *>(smem) + wv * RTW_PAIR_CAP;
+        ws.keys = reinterpret_cast<unsigned long long *>(cells) + wv * 64;
+        ws.kidx = reinterpret_cast<unsigned *>(cells + 4 * 64 * sizeof(unsigned long long)) + wv * 64;
+    }
     unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + (CULL ? cull_exact_count(cull) : 0));
     if (threadIdx.x < P_arg.n_slots) { JobSlot *S0 = sh->slot(threadIdx.x, P_arg.slot_stride); S0->ready_seq = RTW_SLOT_FREE; S0->job = 0u; }
     if (threadIdx.x == 0) { sh->ticket = 0u; sh->cam = cam_arg; sh->P = P_arg; }
@@ -246,7 +267,12 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL>::value)) void trace_ker
         // ---- (S) closest hit over the whole sphere list (src/hit.jl:38-50) ----
         T t_hit = 0;
         int idx = -1;
-        if (has_ray) {
+        if constexpr (MFMA) {
+            if (__any(has_ray)) {
+                if (LDS_SCENE) idx = hit_world_mfma<T>(scene, (const V4 *)lds_geom, ro, rd, has_ray, (T)1e-4, t_hit, ws, lane, clk);
+                else idx = hit_world_mfma<T>(scene, scene.geom, ro, rd, has_ray, (T)1e-4, t_hit, ws, lane, clk);
+            }
+        } else if (has_ray) {
             if (CULL && LDS_SCENE)
                 idx = hit_world_cull<T, 256>(cull, (const V4 *)lds_geom, (const unsigned short *)lds_orig, ro, rd, (T)1e-4,
                                              (T)__builtin_huge_val(), t_hit, my_list, clk);
