@@ -654,18 +654,29 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     const uint4 *pa = w.mf_ops + lane;
     uint4 A1 = pa[0], A2 = pa[64];
     for (int blk = 0; blk < w.mf_blocks; ++blk) {
-        const uint4 N1 = pa[(blk + 1) * 128], N2 = pa[(blk + 1) * 128 + 64];      // (one block of padding)
         unsigned mask = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const rtw_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            const rtw_f16v P1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[h], zero, 0, 0, 0);
-            const rtw_f16v P2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[h], zero, 0, 0, 0);
+        const rtw_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        auto eval = [&](const rtw_f16v &P1, const rtw_f16v &P2, float too_half) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float W = __builtin_fmaf(P1[r], P1[r], P2[r]) - too_h[h];
+                const float W = __builtin_fmaf(P1[r], P1[r], P2[r]) - too_half;
                 mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(W), 31);
             }
+        };
+        {
+            const rtw_f16v P1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[0], zero, 0, 0, 0);
+            const rtw_f16v P2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[0], zero, 0, 0, 0);
+            eval(P1, P2, too_h[0]);
+        }
+        {
+            // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
+            // padding at the end), so only one set of A registers is live during the evaluation
+            const rtw_f16v P1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[1], zero, 0, 0, 0);
+            const rtw_f16v P2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[1], zero, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];
+            __builtin_amdgcn_sched_barrier(0);
+            eval(P1, P2, too_h[1]);
         }
         clk.lap(2);
         unsigned m = ~mask;                               // bit 31 - b: half wave b >> 4, result register b & 15
@@ -688,7 +699,6 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             total += (unsigned)__popcll(act);
         }
         clk.lap(4);
-        A1 = N1; A2 = N2;
     }
     resolve_pairs<T>(src, o, d, tmin, ws, total, lane);
     clk.lap(5);

@@ -4,7 +4,7 @@ usage: python tools/kernel_resources.py [extra hipcc flags]   (cross-compiles fo
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "raytracingweekend.jl_amd", "csrc", "rtw_hip.hip")
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-amdgpu-mfma-vgpr-form",
        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
@@ -18,9 +18,9 @@ for line in out.splitlines():
 print(f"{'kernel':44s} {'VGPR':>5s} {'SGPR':>5s} {'waves':>5s} {'scratch B':>9s} {'vspill':>6s} {'sspill':>6s}")
 for r in rows:
     n = r["name"]
-    m = re.match(r"_ZN3rtw12trace_kernelI([fd])Lb([01])ELb([01])ELb([01])E", n)
+    m = re.match(r"_ZN3rtw12trace_kernelI([fd])Lb([01])ELb([01])ELb([01])ELb([01])E", n)
     if m:
-        label = f"trace<{'f32' if m.group(1) == 'f' else 'f64'}{', profile' if m.group(2) == '1' else ''}{', lds-scene' if m.group(3) == '1' else ', global-scene'}{', cull' if m.group(4) == '1' else ''}>"
+        label = f"trace<{'f32' if m.group(1) == 'f' else 'f64'}{', profile' if m.group(2) == '1' else ''}{', lds-scene' if m.group(3) == '1' else ', global-scene'}{', cull' if m.group(4) == '1' else ''}{', mfma' if m.group(5) == '1' else ''}>"
     elif "unit_kernel" in n:
         label = "unit_kernel<%s>" % ("f32" if "IfE" in n else "f64")
     else:
