@@ -620,29 +620,57 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     const float od = __builtin_fmaf(oz, dz, __builtin_fmaf(oy, dy, ox * dx));
     const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
     const float o1 = (__builtin_fabsf(ox) + __builtin_fabsf(oy)) + __builtin_fabsf(oz);
-    float too = w.mf_sigma2 * __builtin_fmaf(oo, w.mf_oo_keep, -(w.mf_o1_coef * o1));
-    if (!ok) too = has_ray ? -__builtin_huge_valf() : __builtin_huge_valf();        // every sphere / no sphere
+    const float too = w.mf_sigma2 * __builtin_fmaf(oo, w.mf_oo_keep, -(w.mf_o1_coef * o1));       // oo' s^2
     const float z = ok ? 1.0f : 0.0f;
     const float f1[4] = {dx * z, dy * z, dz * z, -(od * w.mf_sc) * z};
-    const float f2[4] = {(ox + ox) * w.mf_sc * z, (oy + oy) * w.mf_sc * z, (oz + oz) * w.mf_sc * z, 32768.0f * z};
-    // Lane (H, j) supplies features 2H and 2H + 1 of ray j (first half wave: h = 0) / ray 32 + j (h = 1)
-    auto half_features = [&](const float (&f)[4], unsigned (&wa)[2], unsigned (&wb)[2]) {
-        const unsigned other = lane ^ 32u;
-        const float g0 = lane_get(f[0], other), g1 = lane_get(f[1], other), g2 = lane_get(f[2], other), g3 = lane_get(f[3], other);
-        // h = 0: lanes < 32 own (f0, f1); lanes >= 32 take (f2, f3) of lane - 32.  h = 1: lanes < 32 take (f0, f1) of lane + 32; lanes >= 32 own (f2, f3)
-        wa[0] = split_f16(H ? g2 : f[0]); wb[0] = split_f16(H ? g3 : f[1]);
-        wa[1] = split_f16(H ? f[2] : g0); wb[1] = split_f16(H ? f[3] : g1);
-    };
-    unsigned a1[2], b1[2], a2[2], b2[2];
-    half_features(f1, a1, b1);
-    half_features(f2, a2, b2);
-    const float too_other = lane_get(too, lane ^ 32u);
-    const float too_h[2] = {H ? too_other : too, H ? too : too_other};
+    const float f2[4] = {(ox + ox) * w.mf_sc * z, (oy + oy) * w.mf_sc * z, (oz + oz) * w.mf_sc * z, z};
+    // Lane (H, j) supplies its half of the K = 16 slots for ray j (first half wave: h = 0) / ray 32 + j (h = 1):
+    //   P1, slots 8H + e: features 2H and 2H + 1 with all four cross terms   A [a1 a1 a2 a2 | a1' a1' a2' a2']  B [b1 b2 b1 b2 | b1' b2' b1' b2']
+    //   P2, H = 0:  2ox.cx and 2oy.cy without the a2 b2 term
+    //               A [c1x c1x c2x c1y c1y c2y 0 0]         B [o1x o2x o1x o1y o2y o1y 0 0]
+    //       H = 1:  2oz.cz likewise; k' s^2 = 2^15 k1 + 2^4 k2 against the ray's constants (0 for a lane that is not ok);
+    //               -oo' s^2 = 2^15 t1 + 2^4 (t2 + t3) against the sphere side's constants (two scales keep the small
+    //               pieces out of the f16 subnormal range: a single 2^15 scale lost 2^-10 / s^2 of the margin and with it
+    //               7 pixels of the 320x180 golden image)
+    //               A [c1z c1z c2z k1 k2 2^15 2^4 2^4]      B [o1z o2z o1z 2^15 2^4 t1 t2 t3]
+    // so W = P1^2 + P2 needs no subtraction: one fma and one v_alignbit per (ray, sphere).
+    const unsigned other = lane ^ 32u;
+    // a lane that is not ok: all features 0 and t1 = +-60000 (exact in f16): W = +-2^15 x 60000 for EVERY sphere
+    const float tx = ok ? -too : (has_ray ? 60000.0f * 32768.0f : -60000.0f * 32768.0f);
+    const float g1[4] = {lane_get(f1[0], other), lane_get(f1[1], other), lane_get(f1[2], other), lane_get(f1[3], other)};
+    const float g2[4] = {lane_get(f2[0], other), lane_get(f2[1], other), lane_get(f2[2], other), lane_get(f2[3], other)};
+    const float gt = lane_get(tx, other);
     rtw_h8 B1[2], B2[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const uint4 q1 = {a1[h], a1[h], b1[h], b1[h]}, q2 = {a2[h], a2[h], b2[h], b2[h]};
+        // the ray of this half wave whose features this lane supplies is its own (h == H) or its partner's
+        const bool own = (unsigned)h == H;
+        const float pa = own ? (H ? f1[2] : f1[0]) : (H ? g1[2] : g1[0]);
+        const float pb = own ? (H ? f1[3] : f1[1]) : (H ? g1[3] : g1[1]);
+        const unsigned wa = split_f16(pa), wb = split_f16(pb);
+        const uint4 q1 = {wa, wa, wb, wb};
         B1[h] = __builtin_bit_cast(rtw_h8, q1);
+        const float qa = own ? (H ? f2[2] : f2[0]) : (H ? g2[2] : g2[0]);      // 2ox s   | 2oz s
+        const float qb = own ? (H ? f2[3] : f2[1]) : (H ? g2[3] : g2[1]);      // 2oy s   | 1 (0: not ok)
+        const float qt = own ? tx : gt;
+        const unsigned xa = split_f16(qa);
+        uint4 q2;
+        if (H == 0u) {
+            const unsigned xb = split_f16(qb);
+            q2.x = xa;                                   // (o1x, o2x)
+            q2.y = (xa & 0xffffu) | (xb << 16);          // (o1x, o1y)
+            q2.z = (xb >> 16) | (xb << 16);              // (o2y, o1y)
+            q2.w = 0u;
+        } else {
+            const _Float16 t1 = (_Float16)(qt * (1.0f / 32768.0f));
+            const float rem = qt - 32768.0f * (float)t1;                  // exact
+            const unsigned x23 = split_f16(rem * (1.0f / 16.0f));         // (t2, t3)
+            const unsigned sb = qb != 0.0f ? 0x7800u : 0u, ss = qb != 0.0f ? 0x4c00u : 0u;      // 2^15, 2^4 as f16
+            q2.x = xa;                                   // (o1z, o2z)
+            q2.y = (xa & 0xffffu) | (sb << 16);          // (o1z, 2^15)
+            q2.z = ss | ((unsigned)__builtin_bit_cast(unsigned short, t1) << 16);   // (2^4, t1)
+            q2.w = x23;                                  // (t2, t3)
+        }
         B2[h] = __builtin_bit_cast(rtw_h8, q2);
     }
     // ---- the result cells ----
@@ -656,17 +684,14 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     for (int blk = 0; blk < w.mf_blocks; ++blk) {
         unsigned mask = 0;
         const rtw_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        auto eval = [&](const rtw_f16v &P1, const rtw_f16v &P2, float too_half) {
+        auto eval = [&](const rtw_f16v &P1, const rtw_f16v &P2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float W = __builtin_fmaf(P1[r], P1[r], P2[r]) - too_half;
-                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(W), 31);
-            }
+            for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(__builtin_fmaf(P1[r], P1[r], P2[r])), 31);
         };
         {
             const rtw_f16v P1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[0], zero, 0, 0, 0);
             const rtw_f16v P2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[0], zero, 0, 0, 0);
-            eval(P1, P2, too_h[0]);
+            eval(P1, P2);
         }
         {
             // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
@@ -676,7 +701,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             __builtin_amdgcn_sched_barrier(0);
             A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];
             __builtin_amdgcn_sched_barrier(0);
-            eval(P1, P2, too_h[1]);
+            eval(P1, P2);
         }
         clk.lap(2);
         unsigned m = ~mask;                               // bit 31 - b: half wave b >> 4, result register b & 15

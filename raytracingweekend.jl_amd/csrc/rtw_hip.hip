@@ -338,20 +338,37 @@ int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h) {
         for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 31, H = lane >> 5;
             const int sph = blk * 32 + 16 * ((i >> 2) & 1) + (((i >> 3) << 2) | (i & 3));
-            float f1[4] = {0, 0, 0, 0}, f2[4] = {0, 0, 0, -32768.0f};         // padding sphere: W = -2^30 - oo' < 0
+            float f1[4] = {0, 0, 0, 0}, f2[3] = {0, 0, 0};
+            double kx = -1073741824.0;                                        // padding sphere: k' s^2 = -2^30: W = -2^30 - oo' s^2 < 0
             if (sph < n) {
                 const double cx = (double)(float)geom[sph].x, cy = (double)(float)geom[sph].y, cz = (double)(float)geom[sph].z;
                 const double r2 = (double)geom[sph].w, c2 = cx * cx + cy * cy + cz * cz;
                 const double Gs = 1.02 * ((2 * A_S + A_r) * c2 + A_r * r2 + 9 * phi_c * (std::fabs(cx) + std::fabs(cy) + std::fabs(cz)) + phi_k);
-                double kx = (r2 - c2 + Gs) * sig2 / 32768.0;
-                float kf = (float)kx;
-                if ((double)kf < kx) kf = std::nextafter(kf, INFINITY);
+                kx = (r2 - c2 + Gs) * sig2;
                 f1[0] = f2[0] = (float)(cx * sc); f1[1] = f2[1] = (float)(cy * sc); f1[2] = f2[2] = (float)(cz * sc);
-                f1[3] = 1.0f; f2[3] = kf;
+                f1[3] = 1.0f;
             }
             uint4 q1, q2;
             split(f1[2 * H], q1.x, q1.y); split(f1[2 * H + 1], q1.z, q1.w);
-            split(f2[2 * H], q2.x, q2.y); split(f2[2 * H + 1], q2.z, q2.w);
+            // P2 (rtw_device.hpp): H = 0 [c1x c1x c2x c1y c1y c2y 0 0], H = 1 [c1z c1z c2z k1 k2 2^15 2^4 2^4]
+            if (H == 0) {
+                unsigned a0, a1, b0, b1;
+                split(f2[0], a0, a1); split(f2[1], b0, b1);                    // (p1, p1), (p2, p2) of each feature
+                const unsigned p1a = a0 & 0xffffu, p2a = a1 & 0xffffu, p1b = b0 & 0xffffu, p2b = b1 & 0xffffu;
+                q2.x = p1a | (p1a << 16); q2.y = p2a | (p1b << 16); q2.z = p1b | (p2b << 16); q2.w = 0u;
+            } else {
+                unsigned a0, a1;
+                split(f2[2], a0, a1);
+                const unsigned p1a = a0 & 0xffffu, p2a = a1 & 0xffffu;
+                // k' s^2 = 2^15 k1 + 2^4 k2, the remainder rounded UP (a larger k' only widens the filter)
+                const _Float16 k1 = (_Float16)(float)(kx / 32768.0);
+                const double rem = (kx - 32768.0 * (double)(float)k1) / 16.0;
+                _Float16 k2 = (_Float16)(float)rem;
+                if ((double)(float)k2 < rem) { unsigned short b; memcpy(&b, &k2, 2); b = (unsigned short)((float)k2 >= 0.0f ? b + 1 : b - 1); memcpy(&k2, &b, 2); }
+                unsigned short b1, b2;
+                memcpy(&b1, &k1, 2); memcpy(&b2, &k2, 2);
+                q2.x = p1a | (p1a << 16); q2.y = p2a | ((unsigned)b1 << 16); q2.z = (unsigned)b2 | (0x7800u << 16); q2.w = 0x4c004c00u;
+            }
             ops[(size_t)blk * 128 + lane] = q1;
             ops[(size_t)blk * 128 + 64 + lane] = q2;
         }
