@@ -551,7 +551,7 @@ typedef _Float16 rtw_h8 __attribute__((ext_vector_type(8)));
 typedef float rtw_f16v __attribute__((ext_vector_type(16)));
 
 struct WaveScratch {
-    unsigned *pairs;              // RTW_PAIR_CAP entries: owner lane << 16 | sphere
+    unsigned *pairs;              // RTW_PAIR_CAP entries: recording lane << 16 | block << 5 | bit (see resolve_pairs)
     unsigned long long *keys;     // 64 entries: Float32 (root bits << 32 | ~sphere); Float64 root bits
     unsigned *kidx;               // Float64 only: 64 entries, sphere + 1
 };
@@ -581,7 +581,8 @@ __device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin,
         const unsigned p = p0 + lane;
         const bool valid = p < n;
         const unsigned e = ws.pairs[valid ? p : 0u];
-        const unsigned owner = e >> 16, sph = e & 0xffffu;
+        // entry = recording lane (H, j) << 16 | block << 5 | b:  ray j + 32 (b >> 4),  sphere 32 block + 16 H + (b & 15)
+        const unsigned owner = ((e >> 16) & 31u) + ((e & 16u) << 1), sph = (e & 0xffefu) + ((e >> 17) & 16u);
         const V3<T> po = {lane_get(o.x, owner), lane_get(o.y, owner), lane_get(o.z, owner)};
         const V3<T> pd = {lane_get(d.x, owner), lane_get(d.y, owner), lane_get(d.z, owner)};
         const V4 s = src[sph];
@@ -677,7 +678,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     if constexpr (sizeof(T) == 4) ws.keys[lane] = ~0ull;
     else { ws.keys[lane] = ~0ull; ws.kidx[lane] = 0u; }
 
-    const unsigned lane_const = ((lane & 31u) << 16) + 16u * H;
+    const unsigned lane_const = lane << 16;
     unsigned total = 0;                                   // wave-uniform
     const uint4 *pa = w.mf_ops + lane;
     uint4 A1 = pa[0], A2 = pa[64];
@@ -705,7 +706,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         }
         clk.lap(2);
         unsigned m = ~mask;                               // bit 31 - b: half wave b >> 4, result register b & 15
-        const unsigned ebase = lane_const + (unsigned)blk * 32u;
+        const unsigned code0 = lane_const + (unsigned)blk * 32u + 31u;      // entry = recording lane << 16 | block << 5 | b
         for (;;) {
             const unsigned long long act = __ballot(m != 0u);
             if (!act) break;
@@ -716,10 +717,10 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
                 clk.lap(5);
             }
             if (m != 0u) {
-                const unsigned b = (unsigned)__clz((int)m);
-                m &= ~(0x80000000u >> b);
-                const unsigned pos = total + __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
-                ws.pairs[pos] = ebase + ((b & 16u) << 17) + (b & 15u);
+                const unsigned z = (unsigned)__builtin_ctz(m);
+                m &= m - 1u;
+                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, total));
+                ws.pairs[pos] = code0 - z;
             }
             total += (unsigned)__popcll(act);
         }
