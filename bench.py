@@ -13,11 +13,17 @@ the zero-padded shard framebuffers are summed onto rank 0 with one RCCL reduce o
 the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline     -- VALU roofline of the only kernel (rtw::trace_kernel): algorithmic flops =
-                  counted ray-sphere tests x 17 flop (/root/reference/src/hit.jl:13-19)
-                  divided by the kernel's HIP-event time on its launch stream, against the FP32
-                  (157.3 TF) or FP64 (78.6 TF) vector peak; `traffic` = HBM bytes per launch from
-                  the committed PMC passes (profiles/), plus the algorithmic HBM figure vs 8 TB/s.
+  roofline     -- roofline of the only kernel (rtw::trace_kernel): algorithmic flops = counted
+                  ray-sphere tests x 17 flop (/root/reference/src/hit.jl:13-19) divided by
+                  the kernel's HIP-event time on its launch stream, against the FP32 vector peak
+                  (157.3 TF), for both precisions: the every-ray-every-sphere part that this count
+                  measures runs as a conservative f16-split filter on the matrix pipe plus an FP32
+                  fma per test, the exact contract arithmetic (FP32 / FP64) only on
+                  its candidates.  `pipes` breaks the executed work down per pipe; `traffic` = HBM
+                  bytes per launch from the committed PMC passes (profiles/), plus the algorithmic
+                  HBM figure vs 8 TB/s.
+  scan_valu    -- the same workload with RTW_FLAG_SCAN_VALU (the contract discriminant for every
+                  sphere on the vector ALUs, the round-1/2 scan): same image, for comparison.
   cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
                   bounded sample of the same workload (same image, fewer spp): the faster of a
                   16-thread leg (`cpu_baseline_16t`, the north star's comparison point) and an
@@ -41,6 +47,8 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
 # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 vector 157.3 TFLOP/s (= 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz);
 # the guide lists no FP64 vector figure: AMD's MI355X datasheet gives 78.6 TFLOP/s (half the FP32 rate).
 VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+MFMA_F16_PEAK_TFLOPS = 2500.0   # same guide: ~2.5 PF dense BF16/FP16 MFMA (2495 TF measured with 32x32x16)
+MFMA_FLOP_PER_TEST = 64         # two v_mfma_f32_32x32x16_f16 products per (ray, sphere): 2 x K=16 x 2 flop
 HBM_PEAK_GBS = 8000.0
 FLOP_PER_TEST = 17              # 3 sub + 5 + 5 (dots) + mul/sub + mul/sub, src/hit.jl:13-19
 
@@ -57,6 +65,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the accelerated / end_to_end / depth16 legs")
     ap.add_argument("--group-cull", action="store_true", help="time the opt-in accelerated scan instead of the plain one")
+    ap.add_argument("--scan-valu", action="store_true", help="time the all-VALU plain scan (RTW_FLAG_SCAN_VALU) instead of the matrix-pipe filter")
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per pixel (0 = library default rule)")
     ap.add_argument("--emulate-shard-of", type=int, default=0,
                     help="analysis only: on ONE GPU render shard 0 of N (what each rank of an N-GPU run does)")
@@ -111,7 +120,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(n_steps, n_warm, *, cull, depth_, record=None):
+    def timed(n_steps, n_warm, *, cull, depth_, record=None, valu=args.scan_valu):
         """W untimed + K timed steps bracketed by barrier + synchronize; returns max-over-ranks seconds."""
         def step(rec):
             def shard(idx, cnt):
@@ -119,7 +128,7 @@ def main():
                     idx, cnt = 0, args.emulate_shard_of
                 renderer.render_into(fb.data_ptr(), W, spp, depth=depth_, seed=1, n_chunks=args.chunks, shard_index=idx,
                                      shard_count=cnt, stream=stream.cuda_stream, group_cull=cull,
-                                     compact=args.collective == "gather")
+                                     compact=args.collective == "gather", scan_valu=valu and not cull)
                 return fb
             R.render_sharded(shard, W, mode=args.collective)    # renders this rank's tiles, ONE collective onto rank 0
             if rec is not None:
@@ -163,6 +172,11 @@ def main():
         accel = {"mode": "RTW_FLAG_GROUP_CULL (kd clusters of 16 + conservative per-ray grown AABB slab test; same image bit for bit)",
                  "value": round(samples_per_step * args.steps / dta / 1e6, 2), "unit": "Msamples/s",
                  "ms_per_step": round(dta / args.steps * 1e3, 3)}
+    scan_valu = None
+    if extras and not args.group_cull and not args.scan_valu:
+        dtv = timed(1, 0, cull=False, depth_=depth, valu=True)
+        scan_valu = {"mode": "RTW_FLAG_SCAN_VALU (contract discriminant for every sphere on the vector ALUs; same image bit for bit)",
+                     "value": round(samples_per_step / dtv / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtv * 1e3, 3)}
     if extras and depth != 16:
         st16 = []
         dt16 = timed(1, 0, cull=args.group_cull, depth_=16, record=st16)
@@ -174,7 +188,8 @@ def main():
     if extras and world == 1 and rank == 0:
         # host-buffer entry point, what the Julia ccall binds: scene upload + render + image D2H, blocking
         t = time.perf_counter()
-        R.render(scene, cam, W, spp, depth=depth, seed=1, n_chunks=args.chunks, device=local_rank, group_cull=args.group_cull)
+        R.render(scene, cam, W, spp, depth=depth, seed=1, n_chunks=args.chunks, device=local_rank, group_cull=args.group_cull,
+                 scan_valu=args.scan_valu)
         te = time.perf_counter() - t
         end_to_end = {"value": round(W * H * spp / te / 1e6, 2), "unit": "Msamples/s", "ms": round(te * 1e3, 3),
                       "kernel_ms": round(R.last_stats()["kernel_ms"], 3),
@@ -185,15 +200,16 @@ def main():
         # sphere tests x 17; duration = mean HIP-event time on the launch stream.
         k_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
         tests_per_launch = sum(tests) / len(tests)
-        peak = VALU_PEAK_TFLOPS[args.dtype]
+        peak = VALU_PEAK_TFLOPS["f32"] if not args.scan_valu else VALU_PEAK_TFLOPS[args.dtype]
         achieved_tflops = tests_per_launch * FLOP_PER_TEST / k_s / 1e12
+        mfma_tflops = tests_per_launch * MFMA_FLOP_PER_TEST / k_s / 1e12
         esize = 8 if args.dtype == "f64" else 4
         alg_bytes = W * H * 3 * esize / world / shard_div + n_spheres * 12 * esize   # framebuffer write + one scene read
         # HBM bytes per launch from the committed PMC passes (profiles/), valid for the exact workload they were taken on
         traffic = traffic_src = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
-            key = f"{args.dtype}_{W}x{H}_{spp}spp_d{depth}_{'cull' if args.group_cull else 'plain'}"
+            key = f"{args.dtype}_{W}x{H}_{spp}spp_d{depth}_{'cull' if args.group_cull else ('valu' if args.scan_valu else 'plain')}"
             if world == 1 and shard_div == 1 and key in tr:
                 traffic, traffic_src = tr[key]["hbm_bytes_per_launch"], tr[key].get("source")
         except Exception:
@@ -201,20 +217,28 @@ def main():
         if args.group_cull:
             achieved_tflops = float("nan")          # the cull mode skips tests: a VALU fraction of never-executed tests would be meaningless
         roofline = {
-            "bound": "valu_" + ("fp64" if args.dtype == "f64" else "fp32"), "kernel": f"rtw::trace_kernel<{'double' if args.dtype == 'f64' else 'float'}>",
+            "bound": ("valu_" + ("fp64" if args.dtype == "f64" else "fp32")) if args.scan_valu else "valu_fp32+mfma_f16",
+            "kernel": f"rtw::trace_kernel<{'double' if args.dtype == 'f64' else 'float'}>",
             "achieved": None if args.group_cull else round(achieved_tflops, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": None if args.group_cull else round(achieved_tflops / peak, 4),
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
             "traffic_source": traffic_src,
             "kernel_ms": round(k_s * 1e3, 3), "tests_per_launch": int(tests_per_launch),
             "flop_per_test": FLOP_PER_TEST, "segments_per_sample": round(all_segments / (samples_per_step * args.steps), 4),
-            "note": "peak = MI355X vector peak of the arithmetic type (FP32 157.3 TF from MI355X_MICROARCH.md; FP64 78.6 TF from the "
-                    "datasheet); the path has no dense contraction, so no MFMA.  achieved = counted ray-sphere tests x 17 flop / kernel time.  "
-                    + ("Float64: every sphere is tested every segment, but pass 1 of the scan is a conservative binary32 filter "
-                       "(12 FP32 instructions per sphere, rigorous margin) and only its candidates get the exact binary64 test, so the "
-                       "algorithmic FP64 flops are not all executed as FP64 instructions (DESIGN.md 6.1)" if args.dtype == "f64" else
-                       "The kernel issues 2.25 cycles per VALU instruction; the test loop is 11 instructions per sphere = 76 % of the "
-                       "instruction stream (DESIGN.md 6.3)"),
+            "pipes": None if (args.group_cull or args.scan_valu) else {
+                "mfma_f16": {"executed_flop_per_test": MFMA_FLOP_PER_TEST, "achieved": round(mfma_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(mfma_tflops / MFMA_F16_PEAK_TFLOPS, 4)},
+                "valu_fp32": {"instructions_per_test": 2, "what": "v_fma_f32 (hb^2 + m) + v_alignbit_b32 (sign bit into the candidate mask)"},
+                "frac_of_fp64_vector_peak": round(achieved_tflops / VALU_PEAK_TFLOPS["f64"], 4) if args.dtype == "f64" else None},
+            "note": "achieved = counted ray-sphere tests x 17 algorithmic flop / kernel time; peak = MI355X FP32 vector peak (157.3 TF, "
+                    "MI355X_MICROARCH.md) for both precisions.  Every sphere is tested against every ray segment, but pass 1 of the scan is a "
+                    "conservative FILTER: the discriminant is bilinear in (ray features) x (sphere features), so two v_mfma_f32_32x32x16_f16 "
+                    "over f16-split features evaluate 32 spheres x 32 rays and the VALU adds one fma + one alignbit per test (rigorous margin, "
+                    "DESIGN.md 6.1); the exact contract arithmetic (17 flop, FP32 or FP64) runs only on the filter's candidates.  So the algorithmic "
+                    "flops are not all executed as vector flops and `frac` can exceed what a pure-VALU kernel could reach (0.50 with "
+                    "RTW_FLAG_SCAN_VALU, see `scan_valu`); f32-input MFMAs were measured to share the FP32 lanes (no gain), f16 MFMAs do not."
+                    if not args.scan_valu else
+                    "all-VALU plain scan (RTW_FLAG_SCAN_VALU): 11 instructions per test (Float32) / 13 binary32 filter instructions (Float64)",
             "hbm": {"algorithmic_bytes": int(alg_bytes), "achieved_GBs": round(alg_bytes / k_s / 1e9, 4),
                     "peak_GBs": HBM_PEAK_GBS, "frac": round(alg_bytes / k_s / 1e9 / HBM_PEAK_GBS, 8)},
         }
@@ -253,12 +277,14 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"scene_random_spheres ({n_spheres} spheres, reseed!() seed 1), t_cam1, {W}x{H}, {spp} spp, "
                                    f"depth {depth}, {jl} ({cfg_name})",
-                       "scan": "group_cull (opt-in)" if args.group_cull else "plain linear scan over all spheres (reference algorithm)",
+                       "scan": "group_cull (opt-in)" if args.group_cull else
+                               ("plain linear scan over all spheres, all on the VALU (RTW_FLAG_SCAN_VALU)" if args.scan_valu else
+                                "plain linear scan over all spheres (reference algorithm): matrix-pipe filter + exact test of its candidates"),
                        "parallelism": f"tile-sharded x{world}" + (f" + 1 RCCL {args.collective}" if world > 1 else ""),
                        "rng": f"Xoroshiro128+ per (pixel, chunk), {stats[0]['n_chunks']} chunks/pixel; exact fixed-point pixel accumulation"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_16t": cpu16,
             "cpu_baseline_all_threads": (legs[-1] if world == 1 and not args.no_cpu_baseline else None), "accelerated": accel,
-            "end_to_end": end_to_end, "depth16": depth16,
+            "scan_valu": scan_valu, "end_to_end": end_to_end, "depth16": depth16,
         }
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)

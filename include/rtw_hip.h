@@ -66,6 +66,13 @@ typedef struct {
  * the image) at [k*64 + (i mod 8) + 8*(j mod 8)]*3 -- instead of the zero-padded full frame: the buffer is
  * ceil((n_tiles - shard_index) / shard_count) * 192 elements and a gather moves 1/shard_count of the frame. */
 #define RTW_FLAG_COMPACT_TILES 2
+/* RTW_FLAG_SCAN_VALU: run the plain scan entirely on the vector ALUs (the contract discriminant for every
+ * sphere and every ray, 11 instructions each).  Default (0): pass 1 of the plain scan is a conservative filter
+ * on the matrix pipe (v_mfma_f32_32x32x16_f16 over f16-split features), ~1.9x faster; the
+ * exact contract test still decides every hit, so the image is the same bit for bit.  For A/B measurements
+ * and as the reference the filter is tested against; also what the library uses by itself for scenes whose
+ * extent the f16 split cannot cover (|coordinates| or radii beyond 2^40 or all below 2^-40). */
+#define RTW_FLAG_SCAN_VALU 4
 
 /* Positional arguments of render() plus the keyword extras of the shim. */
 typedef struct {
@@ -144,7 +151,9 @@ int rtw_stats(rtw_stats_t *out);
  *   op: 0 hit_sphere  1 reflect  2 refract  3 reflectance  4 scatter  5 get_ray  6 skycolor
  *       7 rng_f (uniforms from a stream state)  8 hit_world  9 ray_color
  *       10 hit_world, scene staged in LDS  11 hit_world_cull (RTW_FLAG_GROUP_CULL)
- *       12 exact 64.64 fixed-point accumulation of 8 doubles                                   */
+ *       12 exact 64.64 fixed-point accumulation of 8 doubles
+ *       13 hit_world_mfma (pass 1 on the matrix pipe: the trace kernel's plain scan), scene staged in LDS;
+ *          tmin of ray 0 serves the whole launch, tmax is +inf                                  */
 int rtw_unit_f32(int op, int count, const void *in, void *out, const rtw_scene_f32 *scene,
                  const rtw_camera_f32 *cam);
 int rtw_unit_f64(int op, int count, const void *in, void *out, const rtw_scene_f64 *scene,

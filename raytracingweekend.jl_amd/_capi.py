@@ -119,6 +119,7 @@ def make_camera(cam, T):
 
 FLAG_GROUP_CULL = 1      # include/rtw_hip.h RTW_FLAG_GROUP_CULL
 FLAG_COMPACT_TILES = 2   # include/rtw_hip.h RTW_FLAG_COMPACT_TILES
+FLAG_SCAN_VALU = 4       # include/rtw_hip.h RTW_FLAG_SCAN_VALU
 ABI_VERSION = 2
 
 

@@ -489,7 +489,7 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
-    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES)) return fail(-2, "unknown flags 0x%x", p->flags);
+    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU)) return fail(-2, "unknown flags 0x%x", p->flags);
     // default rule: about 4 samples per chunk, between 16 and 256 chunks (never more than spp):
     // enough items for load balance, few enough stream set-ups (1 sample per chunk costs 7 % at Float64)
     int nch = p->n_chunks > 0 ? p->n_chunks : std::min(p->spp, std::max(16, std::min(256, p->spp / 4)));
@@ -551,7 +551,7 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     const bool lds_scene = geom_bytes <= RTW_LDS_SCENE_MAX_BYTES;
     // the plain scan runs pass 1 on the matrix pipe (RTW_SCAN=valu: the all-VALU scan, for A/B measurements)
     static const bool force_valu = getenv("RTW_SCAN") != nullptr && strcmp(getenv("RTW_SCAN"), "valu") == 0;
-    const bool mfma = !cull && scene->mf_ops != nullptr && !force_valu;
+    const bool mfma = !cull && scene->mf_ops != nullptr && !force_valu && !(p->flags & RTW_FLAG_SCAN_VALU);
     const size_t lds_bytes = list_bytes + shared_bytes + (mfma ? rtw::mfma_cell_bytes<T>() : 0) + (lds_scene ? geom_bytes : 0);
     typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, rtw::CullScene<T>, T *, rtw::DevCounters *);
     kern_t kern;

@@ -16,6 +16,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 
+def pytest_collection_finish(session):
+    """PyTorch-ROCm ships its own HIP runtime; librtw_hip links the system one.  With two runtimes in one process
+    the one that initialises second sees no device, and the tests that hand torch streams / tensors to the library
+    need both: let torch go first whenever GPU tests are about to run."""
+    if any(item.get_closest_marker("gpu") for item in session.items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:      # no torch / no GPU: the tests that need it fail on their own
+            pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (oracle/librtw_oracle.so), built on demand.  Checker only."""

@@ -34,16 +34,38 @@ def gpu_render(g, **over):
     return out.reshape(kw["width"], kw["height"], 3).transpose(1, 0, 2), st
 
 
+@pytest.mark.parametrize("scan", ["matrix", "valu"])
 @pytest.mark.parametrize("name", GOLDEN_CASES)
-def test_image_matches_golden_bit_exact(name):
+def test_image_matches_golden_bit_exact(name, scan):
+    """default: pass 1 of the plain scan on the matrix pipe (a conservative filter, hit_world_mfma);
+    RTW_FLAG_SCAN_VALU: the contract discriminant for every sphere on the VALU.  Same image, same counters."""
     g = load_golden(name)
-    img, st = gpu_render(g)
+    img, st = gpu_render(g, flags=4 if scan == "valu" else 0)
     assert img.dtype == g["image"].dtype and img.shape == g["image"].shape
     bad = img != g["image"]
     assert not bad.any(), f"{bad.sum()} of {bad.size} channels differ; max abs diff {np.abs(img - g['image']).max()}"
     assert st.segments == g["segments"]
     assert st.samples == g["width"] * g["height"] * g["spp"]
     assert st.sphere_tests == g["segments"] * g["flat"]["n"]
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+@pytest.mark.parametrize("log2_scale", [-45, -30, 0, 12, 30, 45])
+def test_matrix_scan_over_extreme_extents(oracle, rtw, T, log2_scale):
+    """the f16-split filter scales lengths by a power of two chosen from the scene's extent; scenes beyond 2^+-40
+    fall back to the VALU scan inside the library.  Whole scene and camera scaled by 2^k: GPU == oracle."""
+    g = load_golden("metal4_96x54_8spp_d16_f32")
+    k = 2.0 ** log2_scale
+    flat = {key: (v.astype(T) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v) for key, v in g["flat"].items()}
+    for key in ("cx", "cy", "cz", "r"):
+        flat[key] = (flat[key].astype(np.float64) * k).astype(T)
+    cam = {key: np.asarray(v, np.float64) * (k if key in ("origin", "lower_left_corner", "horizontal", "vertical", "lens_radius") else 1.0)
+           for key, v in g["cam"].items()}
+    cam = {key: v.astype(T) for key, v in cam.items()}
+    gg = dict(g, flat=flat, cam=cam, image=np.zeros((1, 1, 3), T))
+    img, st = gpu_render(gg, spp=4, n_chunks=2)
+    ref, ost = oracle.render(flat, cam, g["width"], g["height"], 4, T=T, max_depth=g["depth"], seed=g["seed"], n_chunks=2)
+    assert np.array_equal(img, ref, equal_nan=True) and st.segments == ost["segments"]
 
 
 def test_default_chunk_rule_matches_oracle(oracle):
