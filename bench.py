@@ -229,7 +229,13 @@ def main():
                 "mfma_f16": {"executed_flop_per_test": MFMA_FLOP_PER_TEST, "achieved": round(mfma_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(mfma_tflops / MFMA_F16_PEAK_TFLOPS, 4)},
                 "valu_fp32": {"instructions_per_test": 2, "what": "v_fma_f32 (hb^2 + m) + v_alignbit_b32 (sign bit into the candidate mask)"},
-                "frac_of_fp64_vector_peak": round(achieved_tflops / VALU_PEAK_TFLOPS["f64"], 4) if args.dtype == "f64" else None},
+                "frac_of_fp64_vector_peak": round(achieved_tflops / VALU_PEAK_TFLOPS["f64"], 4) if args.dtype == "f64" else None,
+                # what bounds THIS formulation: a SIMD issues either an MFMA (32 cycles per v_mfma_f32_32x32x16_f16, measured: it does not
+                # overlap with VALU issue, tools/ubench_mfma_overlap.hip) or a VALU instruction (2 cycles at the FP32 peak rate).  Per 64
+                # tests (one sphere x one wave): 4 MFMA / 32 spheres x 32 cycles = 4 cycles + 2 VALU x 2 cycles = 4 cycles.
+                "issue_bound": {"simd_cycles_per_64_tests": {"mfma": 4, "valu": 4},
+                                "peak_algorithmic": round(1024 * 2.4e9 / 8 * 64 * FLOP_PER_TEST / 1e12, 1), "unit": "TFLOP/s",
+                                "frac": round(achieved_tflops / (1024 * 2.4e9 / 8 * 64 * FLOP_PER_TEST / 1e12), 4)}},
             "note": "achieved = counted ray-sphere tests x 17 algorithmic flop / kernel time; peak = MI355X FP32 vector peak (157.3 TF, "
                     "MI355X_MICROARCH.md) for both precisions.  Every sphere is tested against every ray segment, but pass 1 of the scan is a "
                     "conservative FILTER: the discriminant is bilinear in (ray features) x (sphere features), so two v_mfma_f32_32x32x16_f16 "
