@@ -258,10 +258,13 @@ def test_group_cull_mode_full_size_and_shards(oracle, rtw):
     assert np.array_equal(a, b)
 
 
-def test_group_cull_large_and_degenerate_scenes(oracle):
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_large_and_degenerate_scenes_in_every_scan_mode(oracle, T):
+    """1 ... 2000 spheres (2000 do not fit the LDS copy: the global-memory instantiations) with coincident spheres,
+    negative radii: group cull (flags 1), matrix-pipe plain scan (0) and all-VALU plain scan (4) all equal the oracle"""
     rng = np.random.default_rng(11)
-    T = np.float32
     g0 = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
+    g0 = dict(g0, cam={k: np.asarray(v).astype(T) for k, v in g0["cam"].items()})
     for n in (1, 3, 5, 2000):
         flat = dict(n=n, cx=rng.uniform(-4, 4, n).astype(T), cy=rng.uniform(-2, 2, n).astype(T),
                     cz=rng.uniform(-9, -2, n).astype(T), r=(rng.uniform(0.1, 0.5, n) * rng.choice([1, -1], n)).astype(T),
@@ -269,7 +272,8 @@ def test_group_cull_large_and_degenerate_scenes(oracle):
                     ag=rng.uniform(0, 1, n).astype(T), ab=rng.uniform(0, 1, n).astype(T), param=np.full(n, 1.5, T))
         flat["cx"][0], flat["cy"][0], flat["cz"][0] = flat["cx"][-1], flat["cy"][-1], flat["cz"][-1]   # coincident spheres: exact ties
         flat["r"][0] = flat["r"][-1]
-        g = dict(g0, flat=flat)
-        img, st = gpu_render(g, width=64, height=36, spp=2, n_chunks=2, max_depth=6, flags=1)
+        g = dict(g0, flat=flat, image=np.zeros((1, 1, 3), T))
         ref, ost = oracle.render(flat, g["cam"], 64, 36, 2, T=T, max_depth=6, seed=g["seed"], n_chunks=2)
-        assert np.array_equal(img, ref) and st.segments == ost["segments"], n
+        for flags in (1, 0, 4):
+            img, st = gpu_render(g, width=64, height=36, spp=2, n_chunks=2, max_depth=6, flags=flags)
+            assert np.array_equal(img, ref) and st.segments == ost["segments"], (n, flags)
