@@ -66,7 +66,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t &s) {
 }
 // the independent stream of (render seed, pixel, sample chunk) -- DESIGN.md section 5
 __device__ __forceinline__ void rng_stream(uint64_t seed, uint64_t pixel, uint64_t chunk, Rng &r) {
-    uint64_t s = seed ^ (0xd1b54a32d192ed03ULL * (pixel + 1)) ^ (0x8cb92ba72f3d8dd7ULL * (chunk + 1));
+    // (the +1 is applied to registers made HERE: written as K * (x + 1), the compiler keeps the two 64-bit addends K in
+    // loop-long register pairs -- spilled ones, in the trace kernel)
+    uint64_t p1 = pixel + 1, c1 = chunk + 1;
+    __asm__ volatile("" : "+v"(p1), "+v"(c1));
+    uint64_t s = seed ^ (0xd1b54a32d192ed03ULL * p1) ^ (0x8cb92ba72f3d8dd7ULL * c1);
     r.x = splitmix64(s);
     r.y = splitmix64(s);
     (void)rng_next(r);
@@ -74,7 +78,10 @@ __device__ __forceinline__ void rng_stream(uint64_t seed, uint64_t pixel, uint64
 // rand(rng, Float32): low 23 bits -> [1,2) - 1;  rand(rng, Float64): low 52 bits -> [1,2) - 1
 __device__ __forceinline__ void trand(Rng &r, float &out) {
     uint32_t bits = ((uint32_t)rng_next(r) & 0x007fffffu) | 0x3f800000u;
-    out = __uint_as_float(bits) - 1.0f;
+    // [1, 2) - 1, as one v_add_f32 with the inline constant: left to the compiler, this subtraction is paired with an
+    // unrelated add into a v_pk_add_f32 whose constant operand (x, -1.0) it then keeps in a spilled register pair --
+    // 0.8 GB of scratch writes per 1080p frame
+    __asm__("v_add_f32_e32 %0, -1.0, %1" : "=v"(out) : "v"(__uint_as_float(bits)));
 }
 __device__ __forceinline__ void trand(Rng &r, double &out) {
     uint64_t bits = (rng_next(r) & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;

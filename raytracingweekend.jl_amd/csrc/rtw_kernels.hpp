@@ -195,7 +195,11 @@ __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned la
         if (valid) break;                                    // (blocks entirely outside the image are skipped)
     }
     if (g != RTW_JOB_EOF) {
-        if (lane < (4u << P.job_shift)) reinterpret_cast<uint4 *>(S->acc(0))[lane] = uint4{0u, 0u, 0u, 0u};   // 64 B per pixel
+        if (lane < (4u << P.job_shift)) {
+            unsigned zero = 0u;
+            __asm__ volatile("" : "+v"(zero));       // (made here: a hoisted zero quad costs 4 loop-long registers)
+            reinterpret_cast<uint4 *>(S->acc(0))[lane] = uint4{zero, zero, zero, zero};   // 64 B per pixel
+        }
         if (lane < 4) S->uv[lane] = (double)(j_base + (int)lane + 1) / (double)P.width;                        // j / W
         else if (lane < 8) S->uv[lane] = (double)(P.height - (i_base + (int)lane - 4 + 1)) / (double)P.height;   // (H - i) / H
         if (lane == 0) {
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             // hand out items of the wave's batch: item p = (pixel p mod job_px, chunk (64 / job_px) b + p / job_px)
             const unsigned long long take_mask = __ballot(need && alive);
             if (take_mask && pool_next < pool_end) {
-                const unsigned rank = (unsigned)__popcll(take_mask & ((1ull << lane) - 1ull));
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(take_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)take_mask, 0u));   // takers below this lane
                 const unsigned p = pool_next + rank;
                 if (need && alive && p < pool_end) {
                     const JobSlot *S = sh->slot(pool_slot, P.slot_stride);
