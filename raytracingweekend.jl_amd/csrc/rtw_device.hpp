@@ -526,33 +526,49 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 
 // ==== pass 1 on the matrix pipe ====================================================================================
 // The discriminant of src/hit.jl:13-18 is BILINEAR in (ray features) x (sphere features):
-//     -hb = [dx dy dz -o.d] . [cx cy cz 1]                       (P1)
-//      m  = [2ox 2oy 2oz 1] . [cx cy cz r^2 - |c|^2]  - |o|^2      (P2 - oo)
-//      D  = hb^2 + m
-// so one v_mfma_f32_32x32x16_f16 per product evaluates 32 spheres x 32 rays, and the VALU is left with fma + sub +
-// v_alignbit per (ray, sphere) instead of the 11 instructions of hit_world's pass 1 (f32-input MFMAs run on the FP32 vector
-// lanes themselves and gain nothing; tools/ubench_mfma_overlap.hip).  Precision: every f32 feature x is split into two f16
-// pieces x = p1 + p2 (+- 2^-22 |x|; f16 subnormals are honoured by the instruction, tools/ubench_mfma_f16_numerics.hip) and
-// the K = 16 slots of the instruction hold the 4 features x 4 cross terms (a1 b1, a1 b2, a2 b1, a2 b2), so the products are
-// exact in the f32 accumulator and the measured accumulation error is <= 2^-21.8 x max|term| (the bound below assumes
-// 2^-20 x sum|terms|).  The result is only a FILTER, like the binary32 filter of hit_world<double>: pass 2 applies the exact
-// contract test to every candidate, so pass 1 must flag a SUPERSET of {contract discriminant >= 0}.  With lengths scaled
-// by the power of two s (mf_sc: |c_k| s <= 2^11), u = 2^-24, eta = 2^-22, beta = 2^-20 and |d|^2 <= 1.001:
-//     |HB_comp - HB|  <= 1.001 (2 eta + beta + 3.01 u) (|c| + |o|) + floors           (split of d, c, o.d; o.d in f32; MFMA)
-//     |M_comp  - M |  <= 2.002 (2 eta + beta) |o||c| + (eta + beta) |k'| + 4.02 u |o|^2 + floors,   k' = r^2 - |c|^2 + Gs
-//     roundings of fma / sub <= 3 u (HB^2 + |M| + |o|^2),   contract vs exact arithmetic <= 20 u (|o - c| + r)^2
-// which sum to  E <= A_S (|o| + |c|)^2 + A_r (r^2 + |c|^2) + floors  with  A_S = 29 x 2^-22,  A_r = 15.5 x 2^-22  (inputs
-// rounded from binary64 add 1.5 x 2^-22: inside the constants used).  The upload stores  k' = r^2 - |c|^2 + Gs  with
-// Gs = 1.02 [(2 A_S' + A_r') |c|^2 + A_r' r^2 + ...],  A_S' = 2^-17, A_r' = 2^-18, and the ray subtracts
-// oo' = |o|^2 (1 - 2.05 x 2^-16) - (floor coefficient) |o|_1, so that  D >= -E_contract  =>  W > 0: sign bit clear.
-// Rays that are not (nearly) unit, not finite or far outside the scene take every sphere as a candidate; lanes without a
-// ray take none.  Lane layout of the instruction (A: row l & 31, k = 8 (l >> 5) + e; C/D: col l & 31, row (reg & 3) +
-// 8 (reg >> 2) + 4 (l >> 5)): lanes l and l + 32 hold the SAME 32 rays of a half wave and different spheres, so the
-// candidates go to a wave-shared list of (owner lane, sphere) pairs in LDS, and pass 2 walks that list 64 pairs at a
-// time whatever the owner (no lane waits for the longest per-lane list any more).  Pass 2 is order-free: the reference's
-// scan returns the minimum over the spheres of their first root in [tmin, inf) and the LAST sphere among exact ties,
-// which is the minimum of the 64-bit keys (root bits, ~sphere) -- an LDS atomic min per candidate (Float64: min on the
-// root, then max on the index among the candidates that equal it).
+//     -hb = [dx dy dz -o.d] . [cx cy cz 1]                                  (P1)
+//      m  = [2ox 2oy 2oz 1 -oo'] . [cx cy cz k' 1],   k' = r^2 - |c|^2 + Gs     (P2)
+//      W  = P1^2 + P2   ~   D = hb^2 - |o - c|^2 + r^2   (+ the margin Gs + Gr, oo' = |o|^2 - Gr)
+// so one v_mfma_f32_32x32x16_f16 per product evaluates 32 spheres x 32 rays and the VALU is left with ONE fma and ONE
+// v_alignbit per (ray, sphere) instead of the 11 instructions of hit_world's pass 1.  (f32-input MFMAs run on the FP32
+// vector lanes themselves and gain nothing; an MFMA and VALU instructions of other waves do not overlap on a SIMD either:
+// tools/ubench_mfma_overlap.hip.  What is gained is instructions: 4 x 32 cycles of MFMA + 64 VALU per 32 spheres x 64 rays
+// instead of 352 VALU.)
+// The result is only a FILTER, like the binary32 filter of hit_world<double>: pass 2 applies the exact contract test to
+// every candidate, so pass 1 must flag a SUPERSET of {contract discriminant >= 0}.
+// Precision.  Every f32 feature x is split into two f16 pieces x = p1 + p2 (|x - p1 - p2| <= 2^-22 |x|, or 2^-25 absolute
+// once p2 is an f16 subnormal -- the instruction honours subnormal inputs, tools/ubench_mfma_f16_numerics.hip) and the
+// K = 16 slots hold the cross terms (P1: a1b1, a1b2, a2b1, a2b2 of its four features; P2: a1b1, a1b2, a2b1 of the three
+// coordinate features and the constant terms below), so every product is exact in the f32 accumulator; the measured
+// accumulation error is <= 2^-21.8 x max|term| (the bound assumes beta = 2^-20 x sum|terms|).  Lengths are scaled by the
+// power of two s = mf_sc (|c_k| s <= 2^11; |o_k| s <= 2^14 for a ray that uses the filter); the two LARGE constants are
+// split over two scales so that no small piece lands in the f16 subnormal range:
+//     k' s^2  = 2^15 k1 + 2^4 k2          against the ray-side constants (2^15, 2^4)  (0 for a ray that is not ok)
+//     -oo' s^2 = 2^15 t1 + 2^4 (t2 + t3)   against the sphere-side constants (2^15, 2^4, 2^4)
+// (with a single 2^15 scale the t2 piece was a subnormal: 2^-10 / s^2 of the margin was lost and with it 7 pixels of the
+// 320x180 golden image -- the scan stress test and the goldens both catch an under-sized margin.)
+// Error budget in unscaled units, u = 2^-24, eta = 2^-22, beta = 2^-20, |d|^2 <= 1.001, S = (|o| + |c|)^2:
+//     |HB_comp - HB| <= 1.001 (2 eta + beta + 3.01 u)(|c| + |o|) + floors    (splits of d, c, o.d; o.d computed in f32; MFMA)
+//     2 |HB| x that                                          <= 13.6 x 2^-22 S
+//     P2: splits + dropped a2b2 + MFMA                       <=  3.5 x 2^-22 S + (eta + beta)(r^2 + |c|^2 + Gs)
+//     |o|^2 in f32, the fma that forms oo', the final fma    <=  2.9 x 2^-22 S + 0.75 x 2^-22 |k'|
+//     contract discriminant vs exact arithmetic (binary32)   <=  15 u |o - c|^2 + 4 u r^2 <= 3.75 x 2^-22 S + 2^-22 r^2
+//     inputs rounded from binary64 (hit_world_mfma<double>)  <=  1.5 x 2^-22 S
+// in all  E <= 25.3 x 2^-22 S + 6.8 x 2^-22 (r^2 + |c|^2) + floors, floors <= 9 phi_c (|o| + |c|) + phi_k, phi_c = 2^-25 / s.
+// With S <= 2 |o|^2 + 2 |c|^2 the margin separates: the upload adds  Gs = 1.02 [(2 A_S + A_r)|c|^2 + A_r r^2 + 9 phi_c |c|_1
+// + phi_k]  to k' (A_S = 32 x 2^-22 = 2^-17, A_r = 12 x 2^-22) and the ray subtracts  oo' = |o|^2 (1 - 1.02 x 2^-16) -
+// 9.18 phi_c |o|_1  (mf_oo_keep, mf_o1_coef), so that  contract discriminant >= 0  =>  W > 0: sign bit clear.
+// Rays that are not (nearly) unit (the reference does not renormalise dielectric reflections), not finite, or farther
+// than 2^14 / s from the origin take EVERY sphere as a candidate (all features 0, t1 = 60000); lanes without a ray take none
+// (t1 = -60000).  Padding spheres carry k' s^2 = -2^30.
+// Lane layout of the instruction (A: row l & 31, k = 8 (l >> 5) + e; C/D: col l & 31, row (reg & 3) + 8 (reg >> 2) +
+// 4 (l >> 5)): lanes l and l + 32 hold the SAME 32 rays of a half wave and different spheres, so the candidates go to a
+// wave-shared list in LDS and pass 2 walks that list 64 candidates at a time whatever their owner (no lane waits for the
+// longest per-lane list any more).  Pass 2 is order-free: the reference's scan (src/hit.jl:38-50, closest shrinking, "<="
+// acceptance) returns the minimum over the spheres of their first root in [tmin, inf) -- the near root if it is >= tmin,
+// else the far root if that is -- and the LAST sphere among exact ties; a sphere whose near root exceeds the running
+// closest cannot win with its far root either.  That is the minimum of the 64-bit keys (root bits, ~sphere): one LDS
+// atomic min per accepted candidate (Float64: min on the root bits, then max on the index among the candidates equal to it).
 #define RTW_PAIR_CAP 512     // (owner, sphere) pairs per wave; a full list is resolved early
 typedef _Float16 rtw_h8 __attribute__((ext_vector_type(8)));
 typedef float rtw_f16v __attribute__((ext_vector_type(16)));
