@@ -98,11 +98,22 @@ template <typename T> __device__ __forceinline__ T random_between(Rng &r, T mn, 
 // one expression serves both; lanes of a wave that need a ball sample and lanes that need a disk
 // sample run the SAME loop (rtw_kernels.hpp phase R), each consuming its own stream exactly as
 // the reference's two separate loops would.
+// random_between(-1, 1) = trand * (1 - (-1)) + (-1) (src/rand.jl:24) in ONE instruction: with f = the [1, 2) float made from
+// the generator's bits, trand = f - 1, 2 trand and 2 trand - 1 are all exact (multiples of 2^-22 / 2^-51 below 2 in
+// magnitude), so fma(f, 2, -3) -- also exact -- has the same bits as the reference's three roundings.
+__device__ __forceinline__ float random_pm1(Rng &r, float) {
+    const uint32_t bits = ((uint32_t)rng_next(r) & 0x007fffffu) | 0x3f800000u;
+    return __builtin_fmaf(__uint_as_float(bits), 2.0f, -3.0f);
+}
+__device__ __forceinline__ double random_pm1(Rng &r, double) {
+    const uint64_t bits = (rng_next(r) & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    return __builtin_fma(__longlong_as_double((long long)bits), 2.0, -3.0);
+}
 template <typename T> __device__ __forceinline__ T reject_trial(Rng &r, bool ball, V3<T> &p) {
-    p.x = random_between(r, T(-1), T(1));
-    p.y = random_between(r, T(-1), T(1));
+    p.x = random_pm1(r, T(0));
+    p.y = random_pm1(r, T(0));
     p.z = T(0);
-    if (ball) p.z = random_between(r, T(-1), T(1));
+    if (ball) p.z = random_pm1(r, T(0));
     return (p.x * p.x + p.y * p.y) + p.z * p.z;
 }
 // normalize(p) when p.p is already known: StaticArrays' inv(norm(p)) * p with norm = sqrt(p.p)
@@ -730,6 +741,20 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         clk.lap(2);
         unsigned m = ~mask;                               // bit 31 - b: half wave b >> 4, result register b & 15
         const unsigned code0 = lane_const + (unsigned)blk * 32u + 31u;      // entry = recording lane << 16 | block << 5 | b
+#ifdef RTW_DUP_EXTRACT   // instruction/time probe: the extraction loop twice (the first run writes the same entries)
+        { unsigned m2 = m, t2 = total;
+          for (;;) {
+              const unsigned long long act2 = __ballot(m2 != 0u);
+              if (!act2 || t2 + 64u > RTW_PAIR_CAP) break;
+              if (m2 != 0u) {
+                  const unsigned z2 = (unsigned)__builtin_ctz(m2);
+                  m2 &= m2 - 1u;
+                  ws.pairs[__builtin_amdgcn_mbcnt_hi((unsigned)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act2, t2))] = code0 - z2;
+              }
+              t2 += (unsigned)__popcll(act2);
+          }
+          __builtin_amdgcn_wave_barrier(); }
+#endif
         for (;;) {
             const unsigned long long act = __ballot(m != 0u);
             if (!act) break;
@@ -750,6 +775,9 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         clk.lap(4);
     }
     resolve_pairs<T>(src, o, d, tmin, ws, total, lane);
+#ifdef RTW_DUP_RESOLVE_PAIRS   // instruction/time probe: the final resolve twice (idempotent: min / max of the same keys)
+    resolve_pairs<T>(src, o, d, tmin, ws, total, lane);
+#endif
     clk.lap(5);
     int idx;
     if constexpr (sizeof(T) == 4) {
