@@ -129,7 +129,8 @@ template <> struct TraceWavesOf<double, true, false> { static constexpr int valu
 template <> struct TraceWavesOf<float, false, true> { static constexpr int value = RTW_TRACE_WAVES_MFMA_F32; };   // 32 result registers per product
 template <> struct TraceWavesOf<double, false, true> { static constexpr int value = RTW_TRACE_WAVES_MFMA_F64; };
 // LDS of the matrix-pipe scan per workgroup (4 waves): the result cells (the pair lists take the place of the per-lane lists)
-template <typename T> __host__ __device__ constexpr size_t mfma_cell_bytes() { return 4 * (64 * sizeof(unsigned long long) + (sizeof(T) == 8 ? 64 * sizeof(unsigned) : 0)); }
+// + per wave the generator states of the 64 items of its current batch (below: "pool"), 16 B each
+template <typename T> __host__ __device__ constexpr size_t mfma_cell_bytes() { return 4 * (64 * sizeof(unsigned long long) + (sizeof(T) == 8 ? 64 * sizeof(unsigned) : 0)) + 4 * 64 * 16; }
 
 // store_job / open_job run once per job.  Inlined: as real calls (noinline) they keep the lane loop's register
 // pressure lower, but every call saves ~20 live VGPRs to scratch -- 2.7 GB of HBM writes per frame (PMC).
@@ -225,6 +226,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
     constexpr size_t cell_bytes = MFMA ? mfma_cell_bytes<T>() : 0;
     V4 *lds_geom = reinterpret_cast<V4 *>(smem + list_bytes + shared_bytes + cell_bytes);
     WaveScratch ws = {nullptr, nullptr, nullptr};
+    [[maybe_unused]] ulonglong2 *pool_rng = nullptr;      // MFMA variants: generator states of the wave's current batch, made by the whole wave
+    [[maybe_unused]] unsigned long long pool_valid = 0;   // ... and which of its 64 items are real (chunk < n_chunks, pixel inside the image)
     if constexpr (MFMA) {
         static_assert(list_bytes == 4 * RTW_PAIR_CAP * sizeof(unsigned), "the pair lists reuse the per-lane list area");
         const unsigned wv = threadIdx.x >> 6;
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         ws.pairs = reinterpret_cast<unsigned *>(smem) + wv * RTW_PAIR_CAP;
         ws.keys = reinterpret_cast<unsigned long long *>(cells) + wv * 64;
         ws.kidx = reinterpret_cast<unsigned *>(cells + 4 * 64 * sizeof(unsigned long long)) + wv * 64;
+        pool_rng = reinterpret_cast<ulonglong2 *>(cells + mfma_cell_bytes<T>() - 4 * 64 * 16) + wv * 64;
     }
     unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + (CULL ? cull_exact_count(cull) : 0));
     if (threadIdx.x < P_arg.n_slots) { JobSlot *S0 = sh->slot(threadIdx.x, P_arg.slot_stride); S0->ready_seq = RTW_SLOT_FREE; S0->job = 0u; }
@@ -354,6 +358,18 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                         pool_slot = sl; pool_b = tk_b;
                         pool_next = 0; pool_end = 64;
                         have_ticket = false;
+                        if constexpr (MFMA) {
+                            // Lane l prepares item l of the batch: setting up a stream is 2 splitmix64 + 1 step (~60 VALU), and a
+                            // wave takes items a few lanes at a time -- almost every iteration for ~6 % of its lanes.
+                            const unsigned px = lane & ((1u << P.job_shift) - 1u), chunk = tk_b * (64u >> P.job_shift) + (lane >> P.job_shift);
+                            const unsigned side = P.job_shift >> 1;
+                            const int i0 = S->i_base + (int)(px & ((1u << side) - 1u)), j0 = S->j_base + (int)(px >> side);
+                            Rng r0;
+                            rng_stream(P.seed, (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0, chunk, r0);
+                            pool_rng[lane] = ulonglong2{r0.x, r0.y};
+                            pool_valid = __ballot((int)chunk < P.n_chunks && ((S->valid >> px) & 1u));
+                            __builtin_amdgcn_wave_barrier();
+                        }
                     }
                 }
             }
@@ -365,11 +381,19 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                 if (need && alive && p < pool_end) {
                     const JobSlot *S = sh->slot(pool_slot, P.slot_stride);
                     const unsigned px = p & ((1u << P.job_shift) - 1u), chunk = pool_b * (64u >> P.job_shift) + (p >> P.job_shift);
-                    if ((int)chunk < P.n_chunks && ((S->valid >> px) & 1u)) {
-                        const unsigned side = P.job_shift >> 1;
-                        const int i0 = S->i_base + (int)(px & ((1u << side) - 1u)), j0 = S->j_base + (int)(px >> side);
-                        const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
-                        rng_stream(P.seed, pix, chunk, rng);
+                    bool real;
+                    if constexpr (MFMA) real = ((pool_valid >> p) & 1ull) != 0ull;
+                    else real = (int)chunk < P.n_chunks && ((S->valid >> px) & 1u);
+                    if (real) {
+                        if constexpr (MFMA) {
+                            const ulonglong2 st = pool_rng[p];
+                            rng.x = st.x; rng.y = st.y;
+                        } else {
+                            const unsigned side = P.job_shift >> 1;
+                            const int i0 = S->i_base + (int)(px & ((1u << side) - 1u)), j0 = S->j_base + (int)(px >> side);
+                            const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
+                            rng_stream(P.seed, pix, chunk, rng);
+                        }
                         const int s0 = (int)chunk * P.chunk_spp;
                         samples_left = min(P.spp, s0 + P.chunk_spp) - s0;
                         jitter = s0 != 0;                                             // sample 1 of the pixel is centred
