@@ -155,6 +155,18 @@ __device__ __forceinline__ void fx_accumulate(unsigned long long *a, double r, d
     }
 }
 
+// One channel of one sample: `acc` = the pixel's accumulators (a[2c], a[2c+1] per channel, a[6] = poison count).
+__device__ __forceinline__ void fx_accumulate_channel(unsigned long long *acc, unsigned c, double v) {
+    unsigned long long lo, hi;
+    if (fx_from_double(v, lo, hi)) {
+        const unsigned long long old = __hip_atomic_fetch_add(&acc[2 * c], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        hi += (old + lo < old) ? 1ull : 0ull;
+        if (hi) __hip_atomic_fetch_add(&acc[2 * c + 1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_fetch_add(&acc[6], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 // The store of one finished job (src/render.jl:40, src/vec.jl:22): lane = (pixel, channel).
 template <typename T>
 __device__ RTW_RARE_ATTR void store_job(const KParams &P, const JobSlot *S, unsigned lane, T *__restrict__ out) {
@@ -297,7 +309,36 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         // ---- (H1) a miss ends the sample: its radiance thr * sky (src/ray_color.jl:36) is added EXACTLY
         //      to the pixel's accumulators in LDS (a path that runs out of depth adds 0: nothing to do) ----
         const bool hit = has_ray && idx >= 0;
-        if (has_ray && idx < 0) {
+        if constexpr (MFMA) {
+            // About a quarter of the lanes end a path per iteration, and each has three channels to convert and add: instead
+            // of three rounds at ~25 % lane utilisation the (lane, channel) tasks are dealt to ALL lanes through the wave's
+            // candidate list area in LDS (free between two scans): one round for up to 21 paths.
+            const bool miss = has_ray && idx < 0;
+            const unsigned long long miss_mask = __ballot(miss);
+            if (miss_mask) {
+                unsigned char *scr = reinterpret_cast<unsigned char *>(ws.pairs);
+                double *task_val = reinterpret_cast<double *>(scr);                           // 192 x 8 B
+                unsigned short *task_acc = reinterpret_cast<unsigned short *>(scr + 1536);    // 192 x 2 B: LDS offset of the pixel's accumulators | channel
+                if (miss) {
+                    const C3 sky = skycolor(rd);
+                    const unsigned k3 = 3u * __builtin_amdgcn_mbcnt_hi((unsigned)(miss_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)miss_mask, 0u));
+                    const unsigned item_ref = ref_depth & RTW_REF_MASK;
+                    const unsigned a0 = (unsigned)(reinterpret_cast<unsigned char *>(sh->slot(item_ref >> 4, P.slot_stride)->acc(item_ref & 15u)) - smem);
+                    task_val[k3] = thr_r * sky.r; task_val[k3 + 1u] = thr_g * sky.g; task_val[k3 + 2u] = thr_b * sky.b;
+                    task_acc[k3] = (unsigned short)a0; task_acc[k3 + 1u] = (unsigned short)(a0 | 1u); task_acc[k3 + 2u] = (unsigned short)(a0 | 2u);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const unsigned n3 = 3u * (unsigned)__popcll(miss_mask);
+                for (unsigned t0 = 0; t0 < n3; t0 += 64u) {
+                    const unsigned t = t0 + lane;
+                    if (t < n3) {
+                        const unsigned ac = task_acc[t];
+                        fx_accumulate_channel(reinterpret_cast<unsigned long long *>(smem + (ac & 0xfff8u)), ac & 7u, task_val[t]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (has_ray && idx < 0) {
             const C3 sky = skycolor(rd);
             const unsigned item_ref = ref_depth & RTW_REF_MASK;
             fx_accumulate(sh->slot(item_ref >> 4, P.slot_stride)->acc(item_ref & 15u), thr_r * sky.r, thr_g * sky.g, thr_b * sky.b);
