@@ -646,7 +646,7 @@ __device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin,
 template <typename T, typename SRC, typename CLK = NoClock>
 __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<T> o, V3<T> d, bool has_ray, T tmin, T &t_hit,
                                               const WaveScratch &ws, unsigned lane, CLK &&clk = NoClock()) {
-    const unsigned H = lane >> 5;
+    // (lane group H = lane >> 5 supplies features 2H, 2H + 1)
     // ---- ray features (binary32) ----
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     const float s2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -669,44 +669,35 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     //               7 pixels of the 320x180 golden image)
     //               A [c1z c1z c2z k1 k2 2^15 2^4 2^4]      B [o1z o2z o1z 2^15 2^4 t1 t2 t3]
     // so W = P1^2 + P2 needs no subtraction: one fma and one v_alignbit per (ray, sphere).
-    const unsigned other = lane ^ 32u;
     // a lane that is not ok: all features 0 and t1 = +-60000 (exact in f16): W = +-2^15 x 60000 for EVERY sphere
     const float tx = ok ? -too : (has_ray ? 60000.0f * 32768.0f : -60000.0f * 32768.0f);
-    const float g1[4] = {lane_get(f1[0], other), lane_get(f1[1], other), lane_get(f1[2], other), lane_get(f1[3], other)};
-    const float g2[4] = {lane_get(f2[0], other), lane_get(f2[1], other), lane_get(f2[2], other), lane_get(f2[3], other)};
-    const float gt = lane_get(tx, other);
-    rtw_h8 B1[2], B2[2];
+    // Every lane makes, for ITS ray, the operand words of both lane groups (H = 0: features 0, 1; H = 1: features 2, 3);
+    // one v_permlane32_swap per word then hands each lane group its words for both half waves:
+    //     swap(X, Y):  X' = [X(0..31) | Y(0..31)],  Y' = [X(32..63) | Y(32..63)]
+    // with X = the group-0 word and Y = the group-1 word of the lane's own ray, X' is the operand of the first half wave
+    // (lane l < 32: its own ray's group-0 word; lane l >= 32: ray l - 32's group-1 word) and Y' that of the second.
+    const unsigned w10 = split_f16(f1[0]), w11 = split_f16(f1[1]), w12 = split_f16(f1[2]), w13 = split_f16(f1[3]);
+    const unsigned x0 = split_f16(f2[0]), x1 = split_f16(f2[1]), x2 = split_f16(f2[2]);
+    const _Float16 t1 = (_Float16)(tx * (1.0f / 32768.0f));
+    const float trem = tx - 32768.0f * (float)t1;                         // exact
+    const unsigned x23 = split_f16(trem * (1.0f / 16.0f));               // (t2, t3)
+    const unsigned sb = ok ? 0x7800u : 0u, ss = ok ? 0x4c00u : 0u;        // the ray's constants 2^15, 2^4 as f16 (0: not ok)
+    const unsigned g0[6] = {w10, w11, x0, (x0 & 0xffffu) | (x1 << 16), (x1 >> 16) | (x1 << 16), 0u};
+    //                      P1 a   P1 b  (o1x,o2x)  (o1x,o1y)              (o2y,o1y)              (0,0)
+    const unsigned g1[6] = {w12, w13, x2, (x2 & 0xffffu) | (sb << 16), ss | ((unsigned)__builtin_bit_cast(unsigned short, t1) << 16), x23};
+    //                      P1 a   P1 b  (o1z,o2z)  (o1z,2^15)             (2^4,t1)                                              (t2,t3)
+    unsigned h0[6], h1[6];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        // the ray of this half wave whose features this lane supplies is its own (h == H) or its partner's
-        const bool own = (unsigned)h == H;
-        const float pa = own ? (H ? f1[2] : f1[0]) : (H ? g1[2] : g1[0]);
-        const float pb = own ? (H ? f1[3] : f1[1]) : (H ? g1[3] : g1[1]);
-        const unsigned wa = split_f16(pa), wb = split_f16(pb);
-        const uint4 q1 = {wa, wa, wb, wb};
-        B1[h] = __builtin_bit_cast(rtw_h8, q1);
-        const float qa = own ? (H ? f2[2] : f2[0]) : (H ? g2[2] : g2[0]);      // 2ox s   | 2oz s
-        const float qb = own ? (H ? f2[3] : f2[1]) : (H ? g2[3] : g2[1]);      // 2oy s   | 1 (0: not ok)
-        const float qt = own ? tx : gt;
-        const unsigned xa = split_f16(qa);
-        uint4 q2;
-        if (H == 0u) {
-            const unsigned xb = split_f16(qb);
-            q2.x = xa;                                   // (o1x, o2x)
-            q2.y = (xa & 0xffffu) | (xb << 16);          // (o1x, o1y)
-            q2.z = (xb >> 16) | (xb << 16);              // (o2y, o1y)
-            q2.w = 0u;
-        } else {
-            const _Float16 t1 = (_Float16)(qt * (1.0f / 32768.0f));
-            const float rem = qt - 32768.0f * (float)t1;                  // exact
-            const unsigned x23 = split_f16(rem * (1.0f / 16.0f));         // (t2, t3)
-            const unsigned sb = qb != 0.0f ? 0x7800u : 0u, ss = qb != 0.0f ? 0x4c00u : 0u;      // 2^15, 2^4 as f16
-            q2.x = xa;                                   // (o1z, o2z)
-            q2.y = (xa & 0xffffu) | (sb << 16);          // (o1z, 2^15)
-            q2.z = ss | ((unsigned)__builtin_bit_cast(unsigned short, t1) << 16);   // (2^4, t1)
-            q2.w = x23;                                  // (t2, t3)
-        }
-        B2[h] = __builtin_bit_cast(rtw_h8, q2);
+    for (int k = 0; k < 6; ++k) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(g0[k], g1[k], false, false);
+        h0[k] = sw[0]; h1[k] = sw[1];
+    }
+    rtw_h8 B1[2], B2[2];
+    {
+        const uint4 q10 = {h0[0], h0[0], h0[1], h0[1]}, q11 = {h1[0], h1[0], h1[1], h1[1]};
+        const uint4 q20 = {h0[2], h0[3], h0[4], h0[5]}, q21 = {h1[2], h1[3], h1[4], h1[5]};
+        B1[0] = __builtin_bit_cast(rtw_h8, q10); B1[1] = __builtin_bit_cast(rtw_h8, q11);
+        B2[0] = __builtin_bit_cast(rtw_h8, q20); B2[1] = __builtin_bit_cast(rtw_h8, q21);
     }
     // ---- the result cells ----
     if constexpr (sizeof(T) == 4) ws.keys[lane] = ~0ull;
