@@ -5,9 +5,6 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/round2; rm -rf $O; mkdir -p $O
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -2
-python bench.py > $O/bench_f32.json 2> $O/bench_f32.err; cut -c1-400 $O/bench_f32.json
-python bench.py --dtype f64 --width 3840 --steps 2 --warmup 1 > $O/bench_f64_4k.json 2> $O/bench_f64_4k.err; cut -c1-400 $O/bench_f64_4k.json
-python bench.py --emulate-shard-of 8 --steps 3 --no-cpu-baseline > $O/bench_f32_shard8.json 2>/dev/null; cut -c1-300 $O/bench_f32_shard8.json
 cd /tmp && export TMPDIR=/tmp
 B32="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
 B64="python $R/bench.py --dtype f64 --width 3840 --steps 1 --warmup 0 --no-cpu-baseline --no-extras"
@@ -58,3 +55,10 @@ for key, tag in (("f32_1920x1080_1000spp_d50_plain", "f32"), ("f32_1920x1080_100
 json.dump(tr, open("$O/hbm_traffic.json", "w"), indent=1)
 print(json.dumps(tr, indent=1))
 PY
+# the bench lines read the HBM traffic of THIS run (box-local copy of the profile; the merged gpurun_out/round2/hbm_traffic.json
+# is what gets committed as profiles/r02_hbm_traffic.json)
+cp $O/hbm_traffic.json $R/profiles/r02_hbm_traffic.json
+cd $R
+python bench.py > $O/bench_f32.json 2> $O/bench_f32.err; cut -c1-400 $O/bench_f32.json
+python bench.py --dtype f64 --width 3840 --steps 2 --warmup 1 > $O/bench_f64_4k.json 2> $O/bench_f64_4k.err; cut -c1-400 $O/bench_f64_4k.json
+python bench.py --emulate-shard-of 8 --steps 3 --no-cpu-baseline > $O/bench_f32_shard8.json 2>/dev/null; cut -c1-300 $O/bench_f32_shard8.json
