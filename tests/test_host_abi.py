@@ -40,6 +40,17 @@ def test_struct_layouts_match_header(rtw):
     assert ctypes.sizeof(_capi.SceneF32) == 80 and _capi.SceneF32.kind.offset == 40
 
 
+def test_flag_constants_match_header(rtw):
+    """the Python mirror, the Julia shim and include/rtw_hip.h agree on rtw_params.flags"""
+    from rtw_amd import _capi
+    header = open(os.path.join(ROOT, "include", "rtw_hip.h")).read()
+    flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+RTW_FLAG_([A-Z_]+)\s+(\d+)", header)}
+    assert flags == {"GROUP_CULL": _capi.FLAG_GROUP_CULL, "COMPACT_TILES": _capi.FLAG_COMPACT_TILES, "SCAN_VALU": _capi.FLAG_SCAN_VALU}
+    assert sorted(flags.values()) == [1, 2, 4]
+    jl = open(os.path.join(ROOT, "julia", "RTWeekendHIP.jl")).read()
+    assert "(group_cull ? 1 : 0) | (scan_valu ? 4 : 0)" in jl
+
+
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
 def test_render_fails_loudly_without_gpu(rtw):
     """No CPU fallback: on a box without a HIP device render() raises instead of producing pixels."""
