@@ -552,7 +552,8 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 // K = 16 slots hold the cross terms (P1: a1b1, a1b2, a2b1, a2b2 of its four features; P2: a1b1, a1b2, a2b1 of the three
 // coordinate features and the constant terms below), so every product is exact in the f32 accumulator; the measured
 // accumulation error is <= 2^-21.8 x max|term| (the bound assumes beta = 2^-20 x sum|terms|).  Lengths are scaled by the
-// power of two s = mf_sc (|c_k| s <= 2^11; |o_k| s <= 2^14 for a ray that uses the filter); the two LARGE constants are
+// power of two s = mf_sc (|c_k| s <= 2^8; |o_k| s <= 2^14 for a ray that uses the filter: up to 64 x the scene's extent);
+// the two LARGE constants are
 // split over two scales so that no small piece lands in the f16 subnormal range:
 //     k' s^2  = 2^15 k1 + 2^4 k2          against the ray-side constants (2^15, 2^4)  (0 for a ray that is not ok)
 //     -oo' s^2 = 2^15 t1 + 2^4 (t2 + t3)   against the sphere-side constants (2^15, 2^4, 2^4)
@@ -565,7 +566,7 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 //     |o|^2 in f32, the fma that forms oo', the final fma    <=  2.9 x 2^-22 S + 0.75 x 2^-22 |k'|
 //     contract discriminant vs exact arithmetic (binary32)   <=  15 u |o - c|^2 + 4 u r^2 <= 3.75 x 2^-22 S + 2^-22 r^2
 //     inputs rounded from binary64 (hit_world_mfma<double>)  <=  1.5 x 2^-22 S
-// in all  E <= 25.3 x 2^-22 S + 6.8 x 2^-22 (r^2 + |c|^2) + floors, floors <= 9 phi_c (|o| + |c|) + phi_k, phi_c = 2^-25 / s.
+// in all  E <= 25.3 x 2^-22 S + 6.8 x 2^-22 (r^2 + |c|^2) + floors, floors <= 9 phi_c (|o| + |c|) + phi_k, phi_c = 2^-25 / s, phi_k = 2 x 2^-21 / s^2 (the 2^4-scaled pieces of k' and oo').
 // With S <= 2 |o|^2 + 2 |c|^2 the margin separates: the upload adds  Gs = 1.02 [(2 A_S + A_r)|c|^2 + A_r r^2 + 9 phi_c |c|_1
 // + phi_k]  to k' (A_S = 32 x 2^-22 = 2^-17, A_r = 12 x 2^-22) and the ray subtracts  oo' = |o|^2 (1 - 1.02 x 2^-16) -
 // 9.18 phi_c |o|_1  (mf_oo_keep, mf_o1_coef), so that  contract discriminant >= 0  =>  W > 0: sign bit clear.

@@ -321,8 +321,11 @@ int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h) {
     int ex = 0;
     (void)std::frexp(emax, &ex);                         // emax <= 2^ex
     if (ex > 40 || ex < -40) return 0;                   // outside what the scaled f16 pieces cover: VALU scan
-    const double sc = std::ldexp(1.0, 11 - ex), sig2 = sc * sc;
-    const double phi_c = std::ldexp(1.0, -25) / sc, phi_k = std::ldexp(1.0, -10) / sig2;
+    // lengths x s: sphere coordinates and radii use 2^8 of the f16 range, ray origins may use 2^14 -- rays up to 64 x the
+    // scene's extent away still take the filter.  phi_c: a coordinate's second f16 piece is a subnormal below 2^-3
+    // (absolute error 2^-25 scaled); phi_k: the same floor for the 2^4-scaled pieces of k' and of the ray's oo'.
+    const double sc = std::ldexp(1.0, 8 - ex), sig2 = sc * sc;
+    const double phi_c = std::ldexp(1.0, -25) / sc, phi_k = std::ldexp(1.0, -20) / sig2;
     const double A_S = std::ldexp(1.0, -17), A_r = std::ldexp(12.0, -22);
     auto split = [](float x, unsigned &w0, unsigned &w1) {
         const _Float16 p1 = (_Float16)x;

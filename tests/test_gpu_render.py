@@ -68,6 +68,20 @@ def test_matrix_scan_over_extreme_extents(oracle, rtw, T, log2_scale):
     assert np.array_equal(img, ref, equal_nan=True) and st.segments == ost["segments"]
 
 
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_far_cameras_inside_and_beyond_the_filter_range(oracle, rtw, T):
+    """the matrix-pipe filter covers ray origins up to 64 x the scene's extent (here 100.5: the ground sphere); farther
+    rays take every sphere as a candidate.  Telephoto cameras at 3 ... 500 x the extent: GPU == oracle."""
+    scene = rtw.scene_4_spheres(elem_type=T)
+    flat = rtw.flatten_scene(scene, T)
+    for dist, vfov in ((300.0, 0.6), (5000.0, 0.04), (20000.0, 0.01), (50000.0, 0.004)):
+        cam = rtw.default_camera((0.3, 0.2 * dist, dist), (0, 0, -1), (0, 1, 0), vfov, 16 / 9, 0.0, dist, elem_type=T)
+        img = rtw.render(scene, cam, 64, 3, depth=8, n_chunks=3)
+        ref, _ = oracle.render(flat, cam, 64, 36, 3, T=T, max_depth=8, seed=1, n_chunks=3)
+        assert np.array_equal(img, ref), dist
+        assert np.unique(ref.reshape(-1, 3), axis=0).shape[0] > 50       # the spheres are in view
+
+
 def test_default_chunk_rule_matches_oracle(oracle):
     g = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
     for spp in (1, 5, 16, 40, 300, 700):
