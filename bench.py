@@ -13,15 +13,19 @@ the zero-padded shard framebuffers are summed onto rank 0 with one RCCL reduce o
 the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline     -- roofline of the only kernel (rtw::trace_kernel): algorithmic flops = counted
-                  ray-sphere tests x 17 flop (/root/reference/src/hit.jl:13-19) divided by
-                  the kernel's HIP-event time on its launch stream, against the FP32 vector peak
-                  (157.3 TF), for both precisions: the every-ray-every-sphere part that this count
-                  measures runs as a conservative f16-split filter on the matrix pipe plus an FP32
-                  fma per test, the exact contract arithmetic (FP32 / FP64) only on
-                  its candidates.  `pipes` breaks the executed work down per pipe; `traffic` = HBM
-                  bytes per launch from the committed PMC passes (profiles/), plus the algorithmic
-                  HBM figure vs 8 TB/s.
+  roofline     -- roofline of the only kernel (rtw::trace_kernel): achieved = algorithmic flops =
+                  counted ray-sphere tests x 17 flop (/root/reference/src/hit.jl:13-19)
+                  divided by the kernel's HIP-event time on its launch stream.  The every-ray-
+                  every-sphere part that this count measures runs as a conservative f16-split filter
+                  on the matrix pipe plus one FP32 fma + one alignbit per test, the
+                  exact contract arithmetic (FP32 / FP64) only on its candidates; a SIMD issues EITHER
+                  an MFMA or a VALU instruction (measured), so `peak` is the issue bound of that
+                  formulation: 4 MFMA cycles + 2 VALU x 2 cycles per 64 tests -> 334.2 algorithmic
+                  TFLOP/s.  `vs_fp32_vector_peak` relates the same achieved figure to the 157.3 TF
+                  vector peak that bounded the all-VALU scan of rounds 1-2 (it can exceed 1 now),
+                  `mfma_f16` gives the executed matrix-pipe flops against the 2.5 PF dense peak.
+                  `traffic` = HBM bytes per launch from the PMC passes (profiles/), plus the
+                  algorithmic HBM figure vs 8 TB/s.
   scan_valu    -- the same workload with RTW_FLAG_SCAN_VALU (the contract discriminant for every
                   sphere on the vector ALUs, the round-1/2 scan): same image, for comparison.
   cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
@@ -200,12 +204,16 @@ def main():
         # sphere tests x 17; duration = mean HIP-event time on the launch stream.
         k_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
         tests_per_launch = sum(tests) / len(tests)
-        peak = VALU_PEAK_TFLOPS["f32"] if not args.scan_valu else VALU_PEAK_TFLOPS[args.dtype]
+        # issue bound of the matrix-pipe formulation: per 64 tests (one sphere x one wave) 4 v_mfma_f32_32x32x16_f16 per 32 spheres x
+        # 32 cycles (MI355X_MICROARCH.md: 32 cyc/SIMD) = 4 cycles, + 2 VALU x 2 cycles (v_fma_f32: 2 cyc/SIMD) = 4 cycles; MFMA and
+        # VALU issue do not overlap on a SIMD (tools/ubench_mfma_overlap.hip, profiles/r02_ubench_mfma.txt)
+        issue_peak = 1024 * 2.4e9 / 8 * 64 * FLOP_PER_TEST / 1e12
+        peak = issue_peak if not args.scan_valu else VALU_PEAK_TFLOPS[args.dtype]
         achieved_tflops = tests_per_launch * FLOP_PER_TEST / k_s / 1e12
         mfma_tflops = tests_per_launch * MFMA_FLOP_PER_TEST / k_s / 1e12
         esize = 8 if args.dtype == "f64" else 4
         alg_bytes = W * H * 3 * esize / world / shard_div + n_spheres * 12 * esize   # framebuffer write + one scene read
-        # HBM bytes per launch from the committed PMC passes (profiles/), valid for the exact workload they were taken on
+        # HBM bytes per launch from the PMC passes (profiles/), valid for the exact workload they were taken on
         traffic = traffic_src = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
@@ -215,36 +223,34 @@ def main():
         except Exception:
             pass
         if args.group_cull:
-            achieved_tflops = float("nan")          # the cull mode skips tests: a VALU fraction of never-executed tests would be meaningless
+            achieved_tflops = float("nan")          # the cull mode skips tests: a fraction of never-executed tests would be meaningless
+        matrix = not (args.group_cull or args.scan_valu)
         roofline = {
-            "bound": ("valu_" + ("fp64" if args.dtype == "f64" else "fp32")) if args.scan_valu else "valu_fp32+mfma_f16",
+            "bound": ("valu_" + ("fp64" if args.dtype == "f64" else "fp32")) if args.scan_valu else "mfma",
+            "bound_detail": None if not matrix else "SIMD issue time shared by v_mfma_f32_32x32x16_f16 (32 cycles each) and FP32 VALU (2 cycles each)",
             "kernel": f"rtw::trace_kernel<{'double' if args.dtype == 'f64' else 'float'}>",
-            "achieved": None if args.group_cull else round(achieved_tflops, 3), "peak": peak, "unit": "TFLOP/s",
+            "achieved": None if args.group_cull else round(achieved_tflops, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": None if args.group_cull else round(achieved_tflops / peak, 4),
+            "peak_derivation": None if not matrix else
+                "1024 SIMDs x 2.4 GHz / (4 MFMA + 4 VALU cycles per 64 tests) x 64 tests x 17 algorithmic flop (cycle counts: MI355X_MICROARCH.md)",
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
             "traffic_source": traffic_src,
             "kernel_ms": round(k_s * 1e3, 3), "tests_per_launch": int(tests_per_launch),
             "flop_per_test": FLOP_PER_TEST, "segments_per_sample": round(all_segments / (samples_per_step * args.steps), 4),
-            "pipes": None if (args.group_cull or args.scan_valu) else {
-                "mfma_f16": {"executed_flop_per_test": MFMA_FLOP_PER_TEST, "achieved": round(mfma_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
-                             "unit": "TFLOP/s", "frac": round(mfma_tflops / MFMA_F16_PEAK_TFLOPS, 4)},
-                "valu_fp32": {"instructions_per_test": 2, "what": "v_fma_f32 (hb^2 + m) + v_alignbit_b32 (sign bit into the candidate mask)"},
-                "frac_of_fp64_vector_peak": round(achieved_tflops / VALU_PEAK_TFLOPS["f64"], 4) if args.dtype == "f64" else None,
-                # what bounds THIS formulation: a SIMD issues either an MFMA (32 cycles per v_mfma_f32_32x32x16_f16, measured: it does not
-                # overlap with VALU issue, tools/ubench_mfma_overlap.hip) or a VALU instruction (2 cycles at the FP32 peak rate).  Per 64
-                # tests (one sphere x one wave): 4 MFMA / 32 spheres x 32 cycles = 4 cycles + 2 VALU x 2 cycles = 4 cycles.
-                "issue_bound": {"simd_cycles_per_64_tests": {"mfma": 4, "valu": 4},
-                                "peak_algorithmic": round(1024 * 2.4e9 / 8 * 64 * FLOP_PER_TEST / 1e12, 1), "unit": "TFLOP/s",
-                                "frac": round(achieved_tflops / (1024 * 2.4e9 / 8 * 64 * FLOP_PER_TEST / 1e12), 4)}},
-            "note": "achieved = counted ray-sphere tests x 17 algorithmic flop / kernel time; peak = MI355X FP32 vector peak (157.3 TF, "
-                    "MI355X_MICROARCH.md) for both precisions.  Every sphere is tested against every ray segment, but pass 1 of the scan is a "
-                    "conservative FILTER: the discriminant is bilinear in (ray features) x (sphere features), so two v_mfma_f32_32x32x16_f16 "
-                    "over f16-split features evaluate 32 spheres x 32 rays and the VALU adds one fma + one alignbit per test (rigorous margin, "
-                    "DESIGN.md 6.1); the exact contract arithmetic (17 flop, FP32 or FP64) runs only on the filter's candidates.  So the algorithmic "
-                    "flops are not all executed as vector flops and `frac` can exceed what a pure-VALU kernel could reach (0.50 with "
-                    "RTW_FLAG_SCAN_VALU, see `scan_valu`); f32-input MFMAs were measured to share the FP32 lanes (no gain), f16 MFMAs do not."
-                    if not args.scan_valu else
-                    "all-VALU plain scan (RTW_FLAG_SCAN_VALU): 11 instructions per test (Float32) / 13 binary32 filter instructions (Float64)",
+            "vs_fp32_vector_peak": None if not matrix else {"peak": VALU_PEAK_TFLOPS["f32"], "frac": round(achieved_tflops / VALU_PEAK_TFLOPS["f32"], 4),
+                                                             "note": "the bound of the all-VALU scan (rounds 1-2: 0.486 / 0.50); the algorithmic flops are "
+                                                                     "no longer executed as vector flops, so this can exceed 1"},
+            "mfma_f16": None if not matrix else {"executed_flop_per_test": MFMA_FLOP_PER_TEST, "achieved": round(mfma_tflops, 1),
+                                                  "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_tflops / MFMA_F16_PEAK_TFLOPS, 4)},
+            "valu_fp32": None if not matrix else {"instructions_per_test": 2, "what": "v_fma_f32 (hb^2 + m) + v_alignbit_b32 (sign bit into the candidate mask)"},
+            "note": "achieved = counted ray-sphere tests x 17 algorithmic flop / kernel time.  Every sphere is tested against every ray segment, but "
+                    "pass 1 of the scan is a conservative FILTER: the discriminant is bilinear in (ray features) x (sphere features), so two "
+                    "v_mfma_f32_32x32x16_f16 over f16-split features evaluate 32 spheres x 32 rays and the VALU adds one fma + one alignbit per test "
+                    "(rigorous margin, DESIGN.md 6.1); the exact contract arithmetic (17 flop, FP32 or FP64) runs only on the filter's candidates.  "
+                    "`scan_valu` is the same workload with every test on the vector ALUs."
+                    if matrix else
+                    ("all-VALU plain scan (RTW_FLAG_SCAN_VALU): 11 instructions per test (Float32) / 13 binary32 filter instructions (Float64)"
+                     if args.scan_valu else "group-cull mode: tests are skipped, no roofline fraction"),
             "hbm": {"algorithmic_bytes": int(alg_bytes), "achieved_GBs": round(alg_bytes / k_s / 1e9, 4),
                     "peak_GBs": HBM_PEAK_GBS, "frac": round(alg_bytes / k_s / 1e9 / HBM_PEAK_GBS, 8)},
         }
