@@ -371,7 +371,7 @@ template <typename T> struct ScanGroup;
 template <> struct ScanGroup<float> { static constexpr int N = 8; };    // 8 x 16 B = 2 x s_load_dwordx16
 template <> struct ScanGroup<double> { static constexpr int N = 4; };   // 4 x 8 floats = 2 x s_load_dwordx16
 
-struct NoClock { __device__ __forceinline__ void lap(int) {} };
+struct NoClock { __device__ __forceinline__ void lap(int) {} __device__ __forceinline__ void count(int, unsigned) {} };
 
 // src/hit.jl:38-50 -- closest hit by linear scan over ALL spheres; `closest` shrinks; a later
 // sphere wins an exact tie.  Same results as the plain loop, organised for the wave:
@@ -732,6 +732,8 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         }
         clk.lap(2);
         unsigned m = ~mask;                               // bit 31 - b: half wave b >> 4, result register b & 15
+        clk.count(7, 1u);                                 // (phase-profile build only: blocks, and blocks without any candidate)
+        if (!__any(m != 0u)) clk.count(6, 1u);
         const unsigned code0 = lane_const + (unsigned)blk * 32u + 31u;      // entry = recording lane << 16 | block << 5 | b
 #ifdef RTW_DUP_EXTRACT   // instruction/time probe: the extraction loop twice (the first run writes the same entries)
         { unsigned m2 = m, t2 = total;

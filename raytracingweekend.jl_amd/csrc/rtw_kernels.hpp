@@ -92,6 +92,7 @@ template <bool ON> struct PhaseClock {
     __device__ __forceinline__ void lap(int k) {
         if (ON) { unsigned long long t = __builtin_readcyclecounter(); acc[k] += t - t0; t0 = t; }
     }
+    __device__ __forceinline__ void count(int k, unsigned n) { if (ON) acc[k] += n; }      // event counters in the spare cells 6, 7
 };
 
 __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned s) {
