@@ -173,7 +173,7 @@ def main():
         # the opt-in accelerated scan (RTW_FLAG_GROUP_CULL, bit-identical image), timed the same way, reported
         # separately: `value` stays the reference's plain linear scan so that the roofline figure means what it says
         dta = timed(args.steps, 1, cull=True, depth_=depth)
-        accel = {"mode": "RTW_FLAG_GROUP_CULL (kd clusters of 16 + conservative per-ray grown AABB slab test; same image bit for bit)",
+        accel = {"mode": "RTW_FLAG_GROUP_CULL (kd-sorted blocks of 32 spheres skipped when no ray of the wave can touch the block's grown box, in front of the matrix-pipe filter; same image bit for bit)",
                  "value": round(samples_per_step * args.steps / dta / 1e6, 2), "unit": "Msamples/s",
                  "ms_per_step": round(dta / args.steps * 1e3, 3)}
     scan_valu = None

@@ -58,8 +58,10 @@ typedef struct {
 } rtw_camera_f64;
 
 /* rtw_params.flags.  RTW_FLAG_GROUP_CULL: opt-in accelerated closest-hit scan:
- * spheres are clustered at upload and clusters whose inflated bounding sphere a ray provably
- * misses are skipped.  Bit-identical images; default (0) is the reference's plain linear scan. */
+ * spheres are clustered at upload (kd clusters with boxes) and spheres that a ray provably cannot hit are never
+ * tested: a block of 32 spatially sorted spheres is skipped when no ray of the wave can touch its box (default),
+ * or, with RTW_FLAG_SCAN_VALU, per ray and cluster of 16 on the vector ALUs (the round-1/2 form).
+ * Bit-identical images; default (0) is the reference's plain linear scan. */
 #define RTW_FLAG_GROUP_CULL 1
 /* RTW_FLAG_COMPACT_TILES (device-resident entry points): write only this shard's 8x8 tiles, tile-major
  * and compact -- local tile k (global tile k*shard_count + shard_index, tiles numbered column-major like
@@ -153,7 +155,8 @@ int rtw_stats(rtw_stats_t *out);
  *       10 hit_world, scene staged in LDS  11 hit_world_cull (RTW_FLAG_GROUP_CULL)
  *       12 exact 64.64 fixed-point accumulation of 8 doubles
  *       13 hit_world_mfma (pass 1 on the matrix pipe: the trace kernel's plain scan), scene staged in LDS;
- *          tmin of ray 0 serves the whole launch, tmax is +inf                                  */
+ *          tmin of ray 0 serves the whole launch, tmax is +inf
+ *       14 the same with block culling (RTW_FLAG_GROUP_CULL on the matrix pipe), cull layout staged in LDS  */
 int rtw_unit_f32(int op, int count, const void *in, void *out, const rtw_scene_f32 *scene,
                  const rtw_camera_f32 *cam);
 int rtw_unit_f64(int op, int count, const void *in, void *out, const rtw_scene_f64 *scene,

@@ -585,6 +585,14 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 typedef _Float16 rtw_h8 __attribute__((ext_vector_type(8)));
 typedef float rtw_f16v __attribute__((ext_vector_type(16)));
 
+// group cull on the matrix pipe: operands in the cull layout's device order, one binary32 box per block of 32 (lo.xyz, -, hi.xyz, -)
+struct MfmaCull {
+    const uint4 *ops;
+    const float *box;
+    int blocks;
+    float cs[3], rs;      // bounding sphere of the small class (the slab margin grows with the distance to it)
+};
+
 struct WaveScratch {
     unsigned *pairs;              // RTW_PAIR_CAP entries: recording lane << 16 | block << 5 | bit (see resolve_pairs)
     unsigned long long *keys;     // 64 entries: Float32 (root bits << 32 | ~sphere); Float64 root bits
@@ -608,8 +616,10 @@ __device__ __forceinline__ double lane_get(double v, unsigned src_lane) {
 }
 
 // Walk n pairs of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
-template <typename T, typename SRC>
-__device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane) {
+struct NoOrig {};
+template <typename T, typename SRC, typename ORIG = NoOrig>
+__device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
+    constexpr bool CULLED = !__is_same(ORIG, NoOrig);      // device order != the caller's order: ties go by orig[], the key carries both
     using V4 = typename Vec4<T>::type;
     __builtin_amdgcn_wave_barrier();
     for (unsigned p0 = 0; p0 < n; p0 += 64u) {
@@ -624,9 +634,12 @@ __device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin,
         T hb, disc, root = 0;
         sphere_disc<T>(s.x, s.y, s.z, s.w, po, pd, hb, disc);
         const bool hit = valid && sphere_root<T>(hb, disc, tmin, (T)__builtin_huge_val(), root);
+        unsigned tie = sph;                                  // larger = later in the caller's list
+        if constexpr (CULLED) tie = ((unsigned)orig[sph] << 16) | sph;
         if constexpr (sizeof(T) == 4) {
             if (hit) {
-                const unsigned long long key = ((unsigned long long)__float_as_uint(root) << 32) | (unsigned long long)(0xffffffffu - sph);
+                const unsigned low = CULLED ? ((0xffffu - (tie >> 16)) << 16) | (tie & 0xffffu) : 0xffffffffu - tie;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(root) << 32) | (unsigned long long)low;
                 __hip_atomic_fetch_min(&ws.keys[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         } else {
@@ -637,16 +650,21 @@ __device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin,
             const unsigned long long cur = ws.keys[owner];
             if (hit && tb == cur && old > tb) ws.kidx[owner] = 0u;              // the candidate that lowered the minimum to its final value of this step
             __builtin_amdgcn_wave_barrier();
-            if (hit && tb == cur) __hip_atomic_fetch_max(&ws.kidx[owner], sph + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (hit && tb == cur) __hip_atomic_fetch_max(&ws.kidx[owner], tie + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __builtin_amdgcn_wave_barrier();
 }
 
 // Closest hit for the rays of a whole wave (every lane calls it, convergently; has_ray = this lane has a ray).
-template <typename T, typename SRC, typename CLK = NoClock>
+// With `mc` (group cull, RTW_FLAG_GROUP_CULL): the spheres come in the cull layout's device order (src, orig), and a block of
+// 32 is skipped when NO ray of the wave can touch its box -- the slab test of hit_world_cull (same conservative margin, in
+// binary32 with the Float32 kappa for both precisions) per lane, then a wave-wide vote.  Returns the DEVICE index.
+template <typename T, typename SRC, typename ORIG = NoOrig, typename CLK = NoClock>
 __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<T> o, V3<T> d, bool has_ray, T tmin, T &t_hit,
-                                              const WaveScratch &ws, unsigned lane, CLK &&clk = NoClock()) {
+                                              const WaveScratch &ws, unsigned lane, CLK &&clk = NoClock(),
+                                              const MfmaCull *mc = nullptr, ORIG orig = ORIG()) {
+    constexpr bool CULLED = !__is_same(ORIG, NoOrig);
     // (lane group H = lane >> 5 supplies features 2H, 2H + 1)
     // ---- ray features (binary32) ----
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
@@ -706,9 +724,44 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
 
     const unsigned lane_const = lane << 16;
     unsigned total = 0;                                   // wave-uniform
-    const uint4 *pa = w.mf_ops + lane;
+    const uint4 *pa = (CULLED ? mc->ops : w.mf_ops) + lane;
+    const int n_blocks = CULLED ? mc->blocks : w.mf_blocks;
+    // group cull: per-ray constants of the slab test (see hit_world_cull for the margin)
+    [[maybe_unused]] float cinv[3] = {0, 0, 0}, cmargin = 0;
+    typedef const float __attribute__((address_space(4))) *cfptr;
+    [[maybe_unused]] cfptr gbox = nullptr;
+    if constexpr (CULLED) {
+        gbox = (cfptr)(uintptr_t)mc->box;
+        const float ex = ox - mc->cs[0], ey = oy - mc->cs[1], ez = oz - mc->cs[2];
+        const float eps_p = (s2 > 1.0f ? s2 - 1.0f : 0.0f) + 2.4e-7f * s2;
+        const float margin = (0.00390625f * (s2 > 1.0f ? s2 : 1.0f) + 2.0f * __builtin_sqrtf(eps_p)) *
+                             ((__builtin_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) + mc->rs) + 1.0f);
+        auto safe_inv = [](float x) { const float e = 1e-9f; const float y = (x < e && x > -e) ? (x < 0.0f ? -e : e) : x; return 1.0f / y; };
+        cinv[0] = safe_inv(dx); cinv[1] = safe_inv(dy); cinv[2] = safe_inv(dz);
+        cmargin = margin;                                 // (o +- margin is formed per block: 6 more VALU, 5 fewer live registers)
+    }
     uint4 A1 = pa[0], A2 = pa[64];
-    for (int blk = 0; blk < w.mf_blocks; ++blk) {
+    for (int blk = 0; blk < n_blocks; ++blk) {
+        if constexpr (CULLED) {
+            const float lx = gbox[8 * blk], ly = gbox[8 * blk + 1], lz = gbox[8 * blk + 2];
+            const float hx = gbox[8 * blk + 4], hy = gbox[8 * blk + 5], hz = gbox[8 * blk + 6];
+            float mg = cmargin;
+            __asm__ volatile("" : "+v"(mg));              // (keeps o +- m from being hoisted into six loop-long registers)
+            const float x0 = (lx - (ox + mg)) * cinv[0], x1 = (hx - (ox - mg)) * cinv[0];      // lo' - o = lo - (o + m), hi' - o = hi - (o - m)
+            const float y0 = (ly - (oy + mg)) * cinv[1], y1 = (hy - (oy - mg)) * cinv[1];
+            const float z0 = (lz - (oz + mg)) * cinv[2], z1 = (hz - (oz - mg)) * cinv[2];
+            const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+            const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+            const float sgn = tf - __builtin_fmaxf(tn, 0.0f);
+            // a ray that does not use the filter (not ok) touches everything; a lane without a ray nothing
+            const bool touch = has_ray && (!ok || !(sgn < 0.0f));
+            clk.count(7, 1u);
+            if (!__any(touch)) {
+                clk.count(6, 1u);
+                A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];      // (keeps the operand pipeline going)
+                continue;
+            }
+        }
         unsigned mask = 0;
         const rtw_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         auto eval = [&](const rtw_f16v &P1, const rtw_f16v &P2) {
@@ -732,8 +785,10 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         }
         clk.lap(2);
         unsigned m = ~mask;                               // bit 31 - b: half wave b >> 4, result register b & 15
-        clk.count(7, 1u);                                 // (phase-profile build only: blocks, and blocks without any candidate)
-        if (!__any(m != 0u)) clk.count(6, 1u);
+        if constexpr (!CULLED) {                          // (phase-profile build only: blocks, and blocks without any candidate)
+            clk.count(7, 1u);
+            if (!__any(m != 0u)) clk.count(6, 1u);
+        }
         const unsigned code0 = lane_const + (unsigned)blk * 32u + 31u;      // entry = recording lane << 16 | block << 5 | b
 #ifdef RTW_DUP_EXTRACT   // instruction/time probe: the extraction loop twice (the first run writes the same entries)
         { unsigned m2 = m, t2 = total;
@@ -754,7 +809,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             if (!act) break;
             if (total + 64u > RTW_PAIR_CAP) {
                 clk.lap(4);
-                resolve_pairs<T>(src, o, d, tmin, ws, total, lane);
+                resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);
                 total = 0;
                 clk.lap(5);
             }
@@ -768,19 +823,20 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         }
         clk.lap(4);
     }
-    resolve_pairs<T>(src, o, d, tmin, ws, total, lane);
+    resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);
 #ifdef RTW_DUP_RESOLVE_PAIRS   // instruction/time probe: the final resolve twice (idempotent: min / max of the same keys)
-    resolve_pairs<T>(src, o, d, tmin, ws, total, lane);
+    resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);
 #endif
     clk.lap(5);
     int idx;
     if constexpr (sizeof(T) == 4) {
         const unsigned long long k = ws.keys[lane];
-        idx = k == ~0ull ? -1 : (int)(0xffffffffu - (unsigned)k);
+        idx = k == ~0ull ? -1 : (CULLED ? (int)((unsigned)k & 0xffffu) : (int)(0xffffffffu - (unsigned)k));
         t_hit = __uint_as_float((unsigned)(k >> 32));
     } else {
         const unsigned long long k = ws.keys[lane];
-        idx = (int)ws.kidx[lane] - 1;
+        const unsigned ki = ws.kidx[lane];
+        idx = ki == 0u ? -1 : (CULLED ? (int)((ki - 1u) & 0xffffu) : (int)ki - 1);
         t_hit = __longlong_as_double((long long)k);
     }
     if (!has_ray) idx = -1;
@@ -830,8 +886,14 @@ template <typename T> struct CullScene {
     int n_big;                             // device indices n_groups_pad*GS .. +n_big-1
     T cs[3], rs;                           // bounding sphere of the small class
     T kappa;
+    const uint4 *mf_ops;                   // group cull on the matrix pipe (hit_world_mfma with MfmaCull): operands in this
+    const float *mf_box;                   //   device order, one binary32 box per block of 32
+    int mf_blocks;
 };
-template <typename T> __host__ __device__ inline int cull_exact_count(const CullScene<T> &c) { return c.n_groups_pad * RTW_CULL_GS + c.n_big; }
+template <typename T> __host__ __device__ inline MfmaCull mfma_cull_of(const CullScene<T> &c) {
+    return MfmaCull{c.mf_ops, c.mf_box, c.mf_blocks, {(float)c.cs[0], (float)c.cs[1], (float)c.cs[2]}, (float)c.rs * 1.000001f + 1e-30f};
+}
+template <typename T> __host__ __device__ inline int cull_exact_count(const CullScene<T> &c) { return c.n_groups_pad * RTW_CULL_GS + ((c.n_big + 31) / 32) * 32; }   // (allocated in whole blocks of 32: dead slots behind the BIG class)
 
 __device__ __forceinline__ float t_min(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float t_max(float a, float b) { return __builtin_fmaxf(a, b); }

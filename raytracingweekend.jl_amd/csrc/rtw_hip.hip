@@ -180,6 +180,9 @@ struct rtw_scene_dev {
     void *mf_ops;    // null: the scene's extent is outside what the f16 split covers (the VALU scan is used)
     int mf_blocks;
     float mf_sc, mf_sigma2, mf_oo_keep, mf_o1_coef, mf_o_max;
+    // group-cull mode on the matrix pipe: the same operands in the cluster-major order + one box per block of 32
+    void *c_mf_ops, *c_mf_box;
+    int c_mf_blocks;
     // opt-in group-cull mode (RTW_FLAG_GROUP_CULL): cluster-major copies
     void *c_bound, *c_exact, *c_mat0, *c_mat1;
     unsigned short *c_orig;
@@ -216,6 +219,9 @@ void kd_split(const SceneT *s, std::vector<int> &ids, int lo, int hi, std::vecto
 }
 
 // cluster-major arrays for the opt-in group-cull scan (rtw_device.hpp, "opt-in accelerated scan")
+template <typename T, typename V4>
+int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, void **ops_out, int *blocks_out);
+
 template <typename T, typename SceneT>
 int build_cull(const SceneT *s, rtw_scene_dev *h) {
     using V4 = typename rtw::Vec4<T>::type;
@@ -236,7 +242,7 @@ int build_cull(const SceneT *s, rtw_scene_dev *h) {
     const int ng = (int)groups.size();
     const int ng_pad = ((ng + pair - 1) / pair) * pair;
     const int n_big = (int)big_ids.size();
-    const int n_exact = ng_pad * GS + n_big;
+    const int n_exact = ng_pad * GS + ((n_big + 31) / 32) * 32;          // whole blocks of 32 (the matrix-pipe scan may list any slot of a block)
     if (n_exact >= 65536) return fail(-5, "too many spheres (%d) for the group-cull layout", n);
     std::vector<T> box((size_t)(ng_pad + RTW_CULL_BG) * 8);            // + one prefetch group
     std::vector<V4> exact(std::max(n_exact, 1)), mat0(std::max(n_exact, 1)), mat1(std::max(n_exact, 1));
@@ -288,6 +294,37 @@ int build_cull(const SceneT *s, rtw_scene_dev *h) {
     HIP_TRY(hipMemcpy(h->c_mat0, mat0.data(), eb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->c_mat1, mat1.data(), eb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->c_orig, orig.data(), ob, hipMemcpyHostToDevice));
+    // Group cull on the matrix pipe (hit_world_mfma<.., CULLED>): the operands in this cluster-major order and one
+    // box per block of 32 = two clusters (dead clusters left out; the BIG class: everything).  Boxes are binary32,
+    // rounded outwards, for both precisions -- the slab test runs in binary32 with the Float32 margin.
+    if (h->mf_ops && n_exact > 0) {
+        if (int rc = build_mfma_operands<T>(exact, n_exact, h, &h->c_mf_ops, &h->c_mf_blocks)) return rc;
+        const int nb = h->c_mf_blocks;
+        std::vector<float> bx((size_t)(nb + 1) * 8, 0.0f);
+        for (int b = 0; b <= nb; ++b) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            bool all = false, any = false;
+            for (int c = 2 * b; c < 2 * b + 2; ++c) {
+                if (c >= ng_pad) { if (b < nb && c * GS < n_exact) all = true; continue; }   // BIG class (device indices >= ng_pad * GS)
+                if (c >= ng) continue;                                                        // dead cluster
+                any = true;
+                for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)box[(size_t)c * 8 + a]); hi[a] = std::max(hi[a], (double)box[(size_t)c * 8 + 4 + a]); }
+            }
+            float *q = &bx[(size_t)b * 8];
+            for (int a = 0; a < 3; ++a) {
+                if (all) { q[a] = -3.0e38f; q[4 + a] = 3.0e38f; }
+                else if (!any) { q[a] = 1e15f; q[4 + a] = 1e15f; }                            // nothing alive: a point far away
+                else {
+                    float l = (float)lo[a], u2 = (float)hi[a];
+                    if ((double)l > lo[a]) l = std::nextafter(l, -INFINITY);
+                    if ((double)u2 < hi[a]) u2 = std::nextafter(u2, INFINITY);
+                    q[a] = l; q[4 + a] = u2;
+                }
+            }
+        }
+        HIP_TRY(hipMalloc(&h->c_mf_box, bx.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(h->c_mf_box, bx.data(), bx.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -300,6 +337,7 @@ rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
     C.n_groups_pad = h->c_groups_pad; C.n_big = h->c_big;
     C.cs[0] = (T)h->c_cs[0]; C.cs[1] = (T)h->c_cs[1]; C.cs[2] = (T)h->c_cs[2]; C.rs = (T)h->c_rs;
     C.kappa = sizeof(T) == 4 ? (T)0.00390625 : (T)2.384185791015625e-07;     // 2^-8 / 2^-22
+    C.mf_ops = (const uint4 *)h->c_mf_ops; C.mf_box = (const float *)h->c_mf_box; C.mf_blocks = h->c_mf_blocks;
     return C;
 }
 
@@ -307,12 +345,16 @@ rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
 // v_mfma_f32_32x32x16_f16, P1 = [cx cy cz 1] s and P2 = [cx cy cz k'] (k' = r^2 - |c|^2 + the sphere's share Gs of the
 // error margin), every feature split into two f16 pieces.  Row i of the instruction holds sphere 16 ((i >> 2) & 1) +
 // (((i >> 3) << 2) | (i & 3)) of the block, so that result register r of lane (H, j) is sphere 16 H + r.
+// `geom`: n entries; entries with r^2 < -1e29 are padding (never a candidate).  *ops_out / *blocks_out receive the device
+// array; the scale constants in `h` depend on the set of spheres only, so both orders of a scene get the same ones.
 template <typename T, typename V4>
-int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h) {
-    h->mf_ops = nullptr; h->mf_blocks = 0;
+int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, void **ops_out, int *blocks_out) {
+    *ops_out = nullptr; *blocks_out = 0;
     if (n <= 0) return 0;
+    auto live = [&](int i) { return i < n && (double)geom[i].w > -1e29; };
     double emax = 0;
     for (int i = 0; i < n; ++i) {
+        if (!live(i)) continue;
         const double r = std::sqrt(std::fabs((double)geom[i].w));
         emax = std::max(emax, std::max(std::max(std::fabs((double)(float)geom[i].x), std::fabs((double)(float)geom[i].y)),
                                        std::max(std::fabs((double)(float)geom[i].z), r)));
@@ -343,7 +385,7 @@ int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h) {
             const int sph = blk * 32 + 16 * ((i >> 2) & 1) + (((i >> 3) << 2) | (i & 3));
             float f1[4] = {0, 0, 0, 0}, f2[3] = {0, 0, 0};
             double kx = -1073741824.0;                                        // padding sphere: k' s^2 = -2^30: W = -2^30 - oo' s^2 < 0
-            if (sph < n) {
+            if (live(sph)) {
                 const double cx = (double)(float)geom[sph].x, cy = (double)(float)geom[sph].y, cz = (double)(float)geom[sph].z;
                 const double r2 = (double)geom[sph].w, c2 = cx * cx + cy * cy + cz * cz;
                 const double Gs = 1.02 * ((2 * A_S + A_r) * c2 + A_r * r2 + 9 * phi_c * (std::fabs(cx) + std::fabs(cy) + std::fabs(cz)) + phi_k);
@@ -375,9 +417,9 @@ int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h) {
             ops[(size_t)blk * 128 + lane] = q1;
             ops[(size_t)blk * 128 + 64 + lane] = q2;
         }
-    HIP_TRY(hipMalloc(&h->mf_ops, ops.size() * sizeof(uint4)));
-    HIP_TRY(hipMemcpy(h->mf_ops, ops.data(), ops.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    h->mf_blocks = nb;
+    HIP_TRY(hipMalloc(ops_out, ops.size() * sizeof(uint4)));
+    HIP_TRY(hipMemcpy(*ops_out, ops.data(), ops.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    *blocks_out = nb;
     h->mf_sc = (float)sc; h->mf_sigma2 = (float)sig2;
     float keep = (float)(1.0 - 1.02 * 2 * A_S);
     if ((double)keep > 1.0 - 1.02 * 2 * A_S) keep = std::nextafter(keep, 0.0f);
@@ -455,7 +497,7 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
         HIP_TRY(hipMalloc(&h->scan, f.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->scan, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (int rc = build_mfma_operands<T>(geom, n, h.get())) return rc;
+    if (int rc = build_mfma_operands<T>(geom, n, h.get(), &h->mf_ops, &h->mf_blocks)) return rc;
     if (int rc = build_cull<T>(s, h.get())) return rc;
     *out = h.release();
     return 0;
@@ -554,11 +596,14 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     const bool lds_scene = geom_bytes <= RTW_LDS_SCENE_MAX_BYTES;
     // the plain scan runs pass 1 on the matrix pipe (RTW_SCAN=valu: the all-VALU scan, for A/B measurements)
     static const bool force_valu = getenv("RTW_SCAN") != nullptr && strcmp(getenv("RTW_SCAN"), "valu") == 0;
-    const bool mfma = !cull && scene->mf_ops != nullptr && !force_valu && !(p->flags & RTW_FLAG_SCAN_VALU);
+    // (group cull: on the matrix pipe too when the scene has the operands; RTW_FLAG_SCAN_VALU selects the all-VALU cull scan)
+    const bool mfma = (cull ? scene->c_mf_ops != nullptr : scene->mf_ops != nullptr) && !force_valu && !(p->flags & RTW_FLAG_SCAN_VALU);
     const size_t lds_bytes = list_bytes + shared_bytes + (mfma ? rtw::mfma_cell_bytes<T>() : 0) + (lds_scene ? geom_bytes : 0);
     typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, rtw::CullScene<T>, T *, rtw::DevCounters *);
     kern_t kern;
-    if (cull && phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true>;
+    if (cull && mfma && phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true, true>;
+    else if (cull && mfma) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true, true>;
+    else if (cull && phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true>;
     else if (cull) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, true> : (kern_t)rtw::trace_kernel<T, false, false, true>;
     else if (mfma && phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, false, true> : (kern_t)rtw::trace_kernel<T, true, false, false, true>;
     else if (mfma) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false, true> : (kern_t)rtw::trace_kernel<T, false, false, false, true>;
@@ -790,7 +835,7 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
     if (op < 0 || op >= rtw::U_NUM_OPS) return fail(-2, "unknown unit op %d", op);
     if (count < 0 || (count > 0 && (!in || !out))) return fail(-1, "null argument");
     if (count == 0) return 0;
-    const bool needs_scene = op == rtw::U_HIT_WORLD || op == rtw::U_RAY_COLOR || op == rtw::U_HIT_WORLD_LDS || op == rtw::U_HIT_WORLD_CULL || op == rtw::U_HIT_WORLD_MFMA;
+    const bool needs_scene = op == rtw::U_HIT_WORLD || op == rtw::U_RAY_COLOR || op == rtw::U_HIT_WORLD_LDS || op == rtw::U_HIT_WORLD_CULL || op == rtw::U_HIT_WORLD_MFMA || op == rtw::U_HIT_WORLD_MFMA_CULL;
     if (needs_scene && !scene) return fail(-1, "op %d needs a scene", op);
     if (op == rtw::U_GET_RAY && !cam) return fail(-1, "op %d needs a camera", op);
     DeviceGuard guard;
@@ -824,7 +869,8 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
     size_t lds_bytes = 0;
     if (op == rtw::U_HIT_WORLD_LDS || op == rtw::U_HIT_WORLD_MFMA) lds_bytes = (size_t)rtw::scene_geom_alloc(S.n, S.n_pad) * sizeof(V4);
     if (op == rtw::U_HIT_WORLD_MFMA && !S.mf_ops) return fail(-5, "the scene has no matrix-pipe scan operands (unit op %d)", op);
-    if (op == rtw::U_HIT_WORLD_CULL) {
+    if (op == rtw::U_HIT_WORLD_MFMA_CULL && !CS.mf_ops) return fail(-5, "the scene has no matrix-pipe cull operands (unit op %d)", op);
+    if (op == rtw::U_HIT_WORLD_CULL || op == rtw::U_HIT_WORLD_MFMA_CULL) {
         const size_t n_cull = (size_t)rtw::cull_exact_count(CS);
         lds_bytes = n_cull * sizeof(V4) + ((n_cull * sizeof(unsigned short) + 15) / 16) * 16;
     }
@@ -871,7 +917,7 @@ int rtw_scene_free(rtw_scene_handle h) {
     if (!h) return 0;
     DeviceGuard guard;
     HIP_IGNORE(hipSetDevice(h->device));
-    void *ptrs[] = {h->geom, h->mat0, h->mat1, h->scan, h->mf_ops, h->c_bound, h->c_exact, h->c_mat0, h->c_mat1, h->c_orig};
+    void *ptrs[] = {h->geom, h->mat0, h->mat1, h->scan, h->mf_ops, h->c_mf_ops, h->c_mf_box, h->c_bound, h->c_exact, h->c_mat0, h->c_mat1, h->c_orig};
     for (void *q : ptrs) if (q) HIP_IGNORE(hipFree(q));
     delete h;
     return 0;

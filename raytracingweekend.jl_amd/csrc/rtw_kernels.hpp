@@ -129,6 +129,8 @@ template <> struct TraceWavesOf<double, true, false> { static constexpr int valu
 #endif
 template <> struct TraceWavesOf<float, false, true> { static constexpr int value = RTW_TRACE_WAVES_MFMA_F32; };   // 32 result registers per product
 template <> struct TraceWavesOf<double, false, true> { static constexpr int value = RTW_TRACE_WAVES_MFMA_F64; };
+template <> struct TraceWavesOf<float, true, true> { static constexpr int value = RTW_TRACE_WAVES_MFMA_F32; };    // group cull on the matrix pipe
+template <> struct TraceWavesOf<double, true, true> { static constexpr int value = RTW_TRACE_WAVES_MFMA_F64; };
 // LDS of the matrix-pipe scan per workgroup (4 waves): the result cells (the pair lists take the place of the per-lane lists)
 // + per wave the generator states of the 64 items of its current batch (below: "pool"), 16 B each
 template <typename T> __host__ __device__ constexpr size_t mfma_cell_bytes() { return 4 * (64 * sizeof(unsigned long long) + (sizeof(T) == 8 ? 64 * sizeof(unsigned) : 0)) + 4 * 64 * 16; }
@@ -227,7 +229,6 @@ __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned la
 template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL, bool MFMA = false>
 __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void trace_kernel(KParams P_arg, Camera<T> cam_arg, DevScene<T> scene,
                                                    CullScene<T> cull, T *__restrict__ out, DevCounters *ctr) {
-    static_assert(!(CULL && MFMA), "the matrix-pipe scan is the plain scan");
     using V4 = typename Vec4<T>::type;
     const unsigned lane = lane_id();
     // LDS: [per-lane candidate lists, stride 256][job slots, ticket, camera][scene geom copy (LDS_SCENE only)]
@@ -288,7 +289,13 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         // ---- (S) closest hit over the whole sphere list (src/hit.jl:38-50) ----
         T t_hit = 0;
         int idx = -1;
-        if constexpr (MFMA) {
+        if constexpr (MFMA && CULL) {
+            if (__any(has_ray)) {
+                const MfmaCull mc = mfma_cull_of(cull);
+                if (LDS_SCENE) idx = hit_world_mfma<T>(scene, (const V4 *)lds_geom, ro, rd, has_ray, (T)1e-4, t_hit, ws, lane, clk, &mc, (const unsigned short *)lds_orig);
+                else idx = hit_world_mfma<T>(scene, cull.exact, ro, rd, has_ray, (T)1e-4, t_hit, ws, lane, clk, &mc, cull.orig);
+            }
+        } else if constexpr (MFMA) {
             if (__any(has_ray)) {
                 if (LDS_SCENE) idx = hit_world_mfma<T>(scene, (const V4 *)lds_geom, ro, rd, has_ray, (T)1e-4, t_hit, ws, lane, clk);
                 else idx = hit_world_mfma<T>(scene, scene.geom, ro, rd, has_ray, (T)1e-4, t_hit, ws, lane, clk);

@@ -14,7 +14,8 @@ enum UnitOp {
     U_HIT_WORLD_CULL = 11,   // hit_world_cull (RTW_FLAG_GROUP_CULL), scene staged in LDS
     U_FX_SUM = 12,           // exact 64.64 accumulation of 8 doubles -> rounded sum, poison count
     U_HIT_WORLD_MFMA = 13,   // hit_world_mfma (pass 1 on the matrix pipe), scene staged in LDS; tmin / tmax of ray 0 serve the whole launch
-    U_NUM_OPS = 14
+    U_HIT_WORLD_MFMA_CULL = 14,   // hit_world_mfma with block culling (RTW_FLAG_GROUP_CULL on the matrix pipe), cull layout staged in LDS
+    U_NUM_OPS = 15
 };
 
 __host__ __device__ inline int unit_in_slots(int op) {
@@ -27,7 +28,7 @@ __host__ __device__ inline int unit_in_slots(int op) {
         case U_GET_RAY: return 4;       // state[2], s, t
         case U_SKYCOLOR: return 3;      // d[3]
         case U_RNG: return 2;           // state[2]
-        case U_HIT_WORLD: case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: case U_HIT_WORLD_MFMA: return 8;     // o[3], d[3], tmin, tmax
+        case U_HIT_WORLD: case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: case U_HIT_WORLD_MFMA: case U_HIT_WORLD_MFMA_CULL: return 8;     // o[3], d[3], tmin, tmax
         case U_RAY_COLOR: return 9;     // state[2], o[3], d[3], depth
         case U_FX_SUM: return 8;        // 8 binary64 values
     }
@@ -43,7 +44,7 @@ __host__ __device__ inline int unit_out_slots(int op) {
         case U_GET_RAY: return 8;       // state[2], o[3], d[3]
         case U_SKYCOLOR: return 3;
         case U_RNG: return 6;           // state[2], 4 uniforms
-        case U_HIT_WORLD: case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: case U_HIT_WORLD_MFMA: return 9;     // idx, t, p[3], n[3], front
+        case U_HIT_WORLD: case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: case U_HIT_WORLD_MFMA: case U_HIT_WORLD_MFMA_CULL: return 9;     // idx, t, p[3], n[3], front
         case U_RAY_COLOR: return 6;     // state[2], colour[3], segments
         case U_FX_SUM: return 2;        // sum, poisoned
     }
@@ -68,7 +69,7 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
     const bool live = gid < count;                          // no early return: the scan is wave-cooperative
     const double *x = in + (size_t)gid * unit_in_slots(op);
     double *y = out + (size_t)gid * unit_out_slots(op);
-    const bool coop = op == U_HIT_WORLD || op == U_RAY_COLOR || op == U_HIT_WORLD_LDS || op == U_HIT_WORLD_CULL || op == U_HIT_WORLD_MFMA;
+    const bool coop = op == U_HIT_WORLD || op == U_RAY_COLOR || op == U_HIT_WORLD_LDS || op == U_HIT_WORLD_CULL || op == U_HIT_WORLD_MFMA || op == U_HIT_WORLD_MFMA_CULL;
     if (!coop && !live) return;
     switch (op) {
         case U_HIT_SPHERE: {
@@ -173,6 +174,33 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
             if (idx >= 0) {
                 const V4 g = scene.geom[idx];
                 const V4 m0 = scene.mat0[idx];
+                HitRec<T> rec;
+                make_hitrec<T>({g.x, g.y, g.z}, m0.x, o, d, t_hit, rec);
+                y[1] = (double)rec.t; st3(y + 2, rec.p); st3(y + 5, rec.n); y[8] = rec.front ? 1.0 : 0.0;
+            }
+        } break;
+        case U_HIT_WORLD_MFMA_CULL: {
+            __shared__ unsigned c_pairs[RTW_PAIR_CAP];
+            __shared__ unsigned long long c_keys[64];
+            __shared__ unsigned c_kidx[64];
+            V4 *lds_geom = reinterpret_cast<V4 *>(u_smem);
+            unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + cull_exact_count(cull));
+            stage_cull_scene<T>(cull, lds_geom, lds_orig);
+            __syncthreads();
+            V3<T> o = {0, 0, 0}, d = {0, 0, 1};
+            if (live) { o = ld3<T>(x); d = ld3<T>(x + 3); }
+            const T tmn = (T)in[6];
+            T t_hit;
+            const WaveScratch ws = {c_pairs, c_keys, c_kidx};
+            const MfmaCull mc = mfma_cull_of(cull);
+            int idx = -1;
+            if (cull.mf_ops) idx = hit_world_mfma<T>(scene, (const V4 *)lds_geom, o, d, live, tmn, t_hit, ws, threadIdx.x & 63u, NoClock(), &mc, (const unsigned short *)lds_orig);
+            if (!live) return;
+            for (int k = 0; k < 9; ++k) y[k] = 0.0;
+            y[0] = (double)(idx >= 0 ? (int)cull.orig[idx] : idx);      // index in the caller's list
+            if (idx >= 0) {
+                const V4 g = cull.exact[idx];
+                const V4 m0 = cull.mat0[idx];
                 HitRec<T> rec;
                 make_hitrec<T>({g.x, g.y, g.z}, m0.x, o, d, t_hit, rec);
                 y[1] = (double)rec.t; st3(y + 2, rec.p); st3(y + 5, rec.n); y[8] = rec.front ? 1.0 : 0.0;

@@ -251,10 +251,12 @@ def test_too_many_spheres_is_an_error():
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_group_cull_mode_is_bit_identical(name):
-    """opt-in accelerated scan (RTW_FLAG_GROUP_CULL): same image, same segment count"""
+    """opt-in accelerated scan (RTW_FLAG_GROUP_CULL), on the matrix pipe (block culling in front of the filter) and in its
+    all-VALU form (| RTW_FLAG_SCAN_VALU): same image, same segment count"""
     g = load_golden(name)
-    img, st = gpu_render(g, flags=1)
-    assert np.array_equal(img, g["image"]) and st.segments == g["segments"]
+    for flags in (1, 5):
+        img, st = gpu_render(g, flags=flags)
+        assert np.array_equal(img, g["image"]) and st.segments == g["segments"], flags
 
 
 def test_group_cull_mode_full_size_and_shards(oracle, rtw):
@@ -275,7 +277,8 @@ def test_group_cull_mode_full_size_and_shards(oracle, rtw):
 @pytest.mark.parametrize("T", [np.float32, np.float64])
 def test_large_and_degenerate_scenes_in_every_scan_mode(oracle, T):
     """1 ... 2000 spheres (2000 do not fit the LDS copy: the global-memory instantiations) with coincident spheres,
-    negative radii: group cull (flags 1), matrix-pipe plain scan (0) and all-VALU plain scan (4) all equal the oracle"""
+    negative radii: group cull on the matrix pipe (flags 1) and on the VALU (5), matrix-pipe plain scan (0) and all-VALU
+    plain scan (4) all equal the oracle"""
     rng = np.random.default_rng(11)
     g0 = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
     g0 = dict(g0, cam={k: np.asarray(v).astype(T) for k, v in g0["cam"].items()})
@@ -288,6 +291,6 @@ def test_large_and_degenerate_scenes_in_every_scan_mode(oracle, T):
         flat["r"][0] = flat["r"][-1]
         g = dict(g0, flat=flat, image=np.zeros((1, 1, 3), T))
         ref, ost = oracle.render(flat, g["cam"], 64, 36, 2, T=T, max_depth=6, seed=g["seed"], n_chunks=2)
-        for flags in (1, 0, 4):
+        for flags in (1, 5, 0, 4):           # group cull on the matrix pipe / on the VALU, plain scan on the matrix pipe / on the VALU
             img, st = gpu_render(g, width=64, height=36, spp=2, n_chunks=2, max_depth=6, flags=flags)
             assert np.array_equal(img, ref) and st.segments == ost["segments"], (n, flags)

@@ -328,8 +328,9 @@ def _stress_rays(rng, flat, m, T, scale):
 def test_scan_stress_plain_lds_and_cull_agree_with_oracle(oracle, T):
     """~10^6 random rays over random scenes (coordinates up to 1e4, |r| from 1e-3 to 1e3, negative
     radii, coincident spheres, origins on surfaces / far away): hit_world from global memory
-    (op 8), from LDS (op 10), hit_world_cull (op 11) and hit_world_mfma (op 13: pass 1 on the matrix pipe, the
-    trace kernel's plain scan) must return the oracle's sphere index and t exactly."""
+    (op 8), from LDS (op 10), hit_world_cull (op 11), hit_world_mfma (op 13: pass 1 on the matrix pipe, the
+    trace kernel's plain scan) and its block-culling form (op 14: RTW_FLAG_GROUP_CULL) must return the oracle's sphere
+    index and t exactly."""
     rng = np.random.default_rng(2024)
     total = 0
     for case, (n, scale, m) in enumerate([(0, 1, 256), (1, 1, 4096), (2, 10, 4096), (7, 10, 65536), (33, 1, 65536),
@@ -339,8 +340,8 @@ def test_scan_stress_plain_lds_and_cull_agree_with_oracle(oracle, T):
         tmin = T(1e-4)
         ref_idx, ref_t = oracle.hit_world_batch(flat, rays, tmin, np.inf, T)
         x = np.concatenate([rays.astype(np.float64), np.full((m, 1), float(tmin)), np.full((m, 1), np.inf)], 1)
-        for op in (8, 10, 11, 13):
-            if op == 13 and n == 0:
+        for op in (8, 10, 11, 13, 14):
+            if op in (13, 14) and n == 0:
                 continue                                   # (no matrix-pipe operands for an empty scene)
             y = run_unit(op, x, 9, T, flat=flat)
             bad = (y[:, 0].astype(np.int64) != ref_idx) | ((ref_idx >= 0) & (y[:, 1] != ref_t.astype(np.float64)))

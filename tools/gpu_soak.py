@@ -55,12 +55,12 @@ while time.time() - t0 < budget:
     camd = {k: np.asarray(getattr(cam, k)) for k in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w", "lens_radius")}
     g = dict(g0, flat=flat, cam=camd, image=np.zeros((1, 1, 3), T))
     ref, ost = O.render(flat, cam, 64, 36, 6, T=T, max_depth=12, seed=seed, n_chunks=3)
-    for flags in (0, 4, 1):
+    for flags in (0, 4, 1, 5):
         img, st = gpu_render(g, width=64, height=36, spp=6, n_chunks=3, max_depth=12, seed=seed, flags=flags)
         imgs += 1
         if not (np.array_equal(img, ref, equal_nan=True) and st.segments == ost["segments"]):
             bad_imgs += 1
             print(f"IMAGE MISMATCH seed {seed} n {n} scale {scale} flags {flags}: {(img != ref).sum()} channels", flush=True)
     seed += 1
-print(f"render soak: {imgs} images (3 scan modes), {bad_imgs} mismatches; total {time.time() - t0:.0f} s", flush=True)
+print(f"render soak: {imgs} images (4 scan modes), {bad_imgs} mismatches; total {time.time() - t0:.0f} s", flush=True)
 sys.exit(1 if (bad_total or bad_imgs) else 0)
