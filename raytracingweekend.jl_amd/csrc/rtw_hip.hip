@@ -210,7 +210,10 @@ void kd_split(const SceneT *s, std::vector<int> &ids, int lo, int hi, std::vecto
     }
     int ax = 0;
     for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
-    int half = ((cnt / 2 + RTW_CULL_GS - 1) / RTW_CULL_GS) * RTW_CULL_GS;      // left part: whole clusters
+    // left part: whole clusters -- and whole PAIRS of clusters while more than one pair is left, so that the blocks of 32 of
+    // the matrix-pipe cull (two consecutive clusters) are always siblings of this tree
+    const int unit = cnt > 2 * RTW_CULL_GS ? 2 * RTW_CULL_GS : RTW_CULL_GS;
+    int half = ((cnt / 2 + unit - 1) / unit) * unit;
     if (half >= cnt) half = cnt - 1;
     auto key = [&](int i) { return ax == 0 ? (double)s->cx[i] : ax == 1 ? (double)s->cy[i] : (double)s->cz[i]; };
     std::nth_element(ids.begin() + lo, ids.begin() + lo + half, ids.begin() + hi, [&](int a, int b) { return key(a) < key(b); });
