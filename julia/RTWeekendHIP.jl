@@ -70,8 +70,8 @@ Drop-in for `RayTracingWeekend.render` (src/render.jl:8-44) on MI355X.  Keyword 
 `depth=16` is the reference's hard-wired `ray_color` default (src/ray_color.jl:14).
 `devices=:all` uses every visible GPU, `devices=[0, 1, 2]` the listed ones (the 8x8 tiles are dealt
 round-robin to the devices inside the library; the image is identical for any device list).
-`group_cull=true` selects the opt-in accelerated scan (RTW_FLAG_GROUP_CULL), `scan_valu=true` the all-VALU plain scan
-(RTW_FLAG_SCAN_VALU, for A/B measurements): same image bit for bit in every mode.
+`group_cull=true` selects the opt-in culling scan (RTW_FLAG_GROUP_CULL), `scan_valu=true` the all-VALU form of either
+scan (RTW_FLAG_SCAN_VALU, for A/B measurements): same image bit for bit in every mode.
 """
 function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=1;
                 depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, group_cull=false, scan_valu=false) where T <: Union{Float32,Float64}
