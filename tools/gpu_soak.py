@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak test of the plain scan's matrix-pipe filter: random scans (unit ops 13 vs the oracle) with fresh seeds for a
+"""Soak test of the matrix-pipe filter: random scans (unit ops 13 and 14 vs the oracle) with fresh seeds for a
 given number of seconds, then random small renders in every scan mode vs the oracle.
 usage: python tools/gpu_soak.py [seconds=300] [first_seed=1000]   (needs the GPU; prints one summary line per round)"""
 import os, sys, time
@@ -30,11 +30,13 @@ while time.time() - t0 < budget * 0.7:
     tmin = T(1e-4)
     ref_idx, ref_t = O.hit_world_batch(flat, rays, tmin, np.inf, T)
     x = np.concatenate([rays.astype(np.float64), np.full((m, 1), float(tmin)), np.full((m, 1), np.inf)], 1)
-    y = run_unit(13, x, 9, T, flat=flat)
-    bad = (y[:, 0].astype(np.int64) != ref_idx) | ((ref_idx >= 0) & (y[:, 1] != ref_t.astype(np.float64)))
-    rays_total += m; bad_total += int(bad.sum()); rounds += 1
-    if bad.any():
-        print(f"MISMATCH seed {seed} n {n} scale {scale} T {T.__name__}: {int(bad.sum())} rays, first {np.flatnonzero(bad)[:5]}", flush=True)
+    for op in (13, 14):                      # the matrix-pipe scan and its block-culling form
+        y = run_unit(op, x, 9, T, flat=flat)
+        bad = (y[:, 0].astype(np.int64) != ref_idx) | ((ref_idx >= 0) & (y[:, 1] != ref_t.astype(np.float64)))
+        rays_total += m; bad_total += int(bad.sum())
+        if bad.any():
+            print(f"MISMATCH op {op} seed {seed} n {n} scale {scale} T {T.__name__}: {int(bad.sum())} rays, first {np.flatnonzero(bad)[:5]}", flush=True)
+    rounds += 1
     seed += 1
 print(f"scan soak: {rounds} rounds, {rays_total} rays, {bad_total} mismatches, {time.time() - t0:.0f} s", flush=True)
 
