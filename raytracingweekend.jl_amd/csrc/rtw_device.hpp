@@ -536,42 +536,54 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 }
 
 // ==== pass 1 on the matrix pipe ====================================================================================
-// The discriminant of src/hit.jl:13-18 is BILINEAR in (ray features) x (sphere features):
-//     -hb = [dx dy dz -o.d] . [cx cy cz 1]                                  (P1)
-//      m  = [2ox 2oy 2oz 1 -oo'] . [cx cy cz k' 1],   k' = r^2 - |c|^2 + Gs     (P2)
-//      W  = P1^2 + P2   ~   D = hb^2 - |o - c|^2 + r^2   (+ the margin Gs + Gr, oo' = |o|^2 - Gr)
-// so one v_mfma_f32_32x32x16_f16 per product evaluates 32 spheres x 32 rays and the VALU is left with ONE fma and ONE
-// v_alignbit per (ray, sphere) instead of the 11 instructions of hit_world's pass 1.  (f32-input MFMAs run on the FP32
-// vector lanes themselves and gain nothing; an MFMA and VALU instructions of other waves do not overlap on a SIMD either:
-// tools/ubench_mfma_overlap.hip.  What is gained is instructions: 4 x 32 cycles of MFMA + 64 VALU per 32 spheres x 64 rays
-// instead of 352 VALU.)
+// The discriminant of src/hit.jl:13-18, D = (d.(o - c))^2 - |o - c|^2 + r^2, expanded around the ray's scalar q = d.o and
+// the vector p = o - q d (an algebraic identity, no unit-length assumption):
+//     D = (d.c)^2 + 2 p.c + (q^2 - |o|^2) + (r^2 - |c|^2)
+// Every term is BILINEAR in (ray features) x (sphere features) -- the square (d.c)^2 = sum_ij (d_i d_j)(c_i c_j) through its six
+// distinct products -- so ONE K = 32 contraction gives the whole filter value
+//     W = [2dx^2 2dy^2 2dz^2 4dxdy 4dxdz 4dydz | 2p | 1 | q^2 - oo'] . [cx^2 cy^2 cz^2 cxcy cxcz cycz (x 1/2) | c | k' | 1]
+// (k' = r^2 - |c|^2 + Gs, oo' = |o|^2 - Gr: the sphere's and the ray's shares of the error margin), computed by two chained
+// v_mfma_f32_32x32x16_f16 (the second accumulates onto the first) for 32 spheres x 32 rays.  The VALU is left with ONE
+// instruction per (ray, sphere) -- the v_alignbit that collects the sign -- instead of the 11 instructions of hit_world's
+// pass 1 (round 2 formed W = P1^2 + P2 from two separate products: one v_fma_f32 more per test, 22 % of the kernel's VALU
+// instructions, and 16 more result registers).  An MFMA and VALU instructions do not overlap on a SIMD, whichever wave they
+// come from and however they are interleaved (tools/ubench_mfma_overlap.hip, tools/ubench_mfma_pipe.hip): the scan costs
+// the SUM of its MFMA and VALU issue time, so the instruction count is what there is to gain.
 // The result is only a FILTER, like the binary32 filter of hit_world<double>: pass 2 applies the exact contract test to
 // every candidate, so pass 1 must flag a SUPERSET of {contract discriminant >= 0}.
-// Precision.  Every f32 feature x is split into two f16 pieces x = p1 + p2 (|x - p1 - p2| <= 2^-22 |x|, or 2^-25 absolute
-// once p2 is an f16 subnormal -- the instruction honours subnormal inputs, tools/ubench_mfma_f16_numerics.hip) and the
-// K = 16 slots hold the cross terms (P1: a1b1, a1b2, a2b1, a2b2 of its four features; P2: a1b1, a1b2, a2b1 of the three
-// coordinate features and the constant terms below), so every product is exact in the f32 accumulator; the measured
-// accumulation error is <= 2^-21.8 x max|term| (the bound assumes beta = 2^-20 x sum|terms|).  Lengths are scaled by the
-// power of two s = mf_sc (|c_k| s <= 2^8; |o_k| s <= 2^14 for a ray that uses the filter: up to 64 x the scene's extent);
-// the two LARGE constants are
-// split over two scales so that no small piece lands in the f16 subnormal range:
-//     k' s^2  = 2^15 k1 + 2^4 k2          against the ray-side constants (2^15, 2^4)  (0 for a ray that is not ok)
-//     -oo' s^2 = 2^15 t1 + 2^4 (t2 + t3)   against the sphere-side constants (2^15, 2^4, 2^4)
-// (with a single 2^15 scale the t2 piece was a subnormal: 2^-10 / s^2 of the margin was lost and with it 7 pixels of the
-// 320x180 golden image -- the scan stress test and the goldens both catch an under-sized margin.)
-// Error budget in unscaled units, u = 2^-24, eta = 2^-22, beta = 2^-20, |d|^2 <= 1.001, S = (|o| + |c|)^2:
-//     |HB_comp - HB| <= 1.001 (2 eta + beta + 3.01 u)(|c| + |o|) + floors    (splits of d, c, o.d; o.d computed in f32; MFMA)
-//     2 |HB| x that                                          <= 13.6 x 2^-22 S
-//     P2: splits + dropped a2b2 + MFMA                       <=  3.5 x 2^-22 S + (eta + beta)(r^2 + |c|^2 + Gs)
-//     |o|^2 in f32, the fma that forms oo', the final fma    <=  2.9 x 2^-22 S + 0.75 x 2^-22 |k'|
-//     contract discriminant vs exact arithmetic (binary32)   <=  15 u |o - c|^2 + 4 u r^2 <= 3.75 x 2^-22 S + 2^-22 r^2
-//     inputs rounded from binary64 (hit_world_mfma<double>)  <=  1.5 x 2^-22 S
-// in all  E <= 25.3 x 2^-22 S + 6.8 x 2^-22 (r^2 + |c|^2) + floors, floors <= 9 phi_c (|o| + |c|) + phi_k, phi_c = 2^-25 / s, phi_k = 2 x 2^-21 / s^2 (the 2^4-scaled pieces of k' and oo').
-// With S <= 2 |o|^2 + 2 |c|^2 the margin separates: the upload adds  Gs = 1.02 [(2 A_S + A_r)|c|^2 + A_r r^2 + 9 phi_c |c|_1
-// + phi_k]  to k' (A_S = 32 x 2^-22 = 2^-17, A_r = 12 x 2^-22) and the ray subtracts  oo' = |o|^2 (1 - 1.02 x 2^-16) -
-// 9.18 phi_c |o|_1  (mf_oo_keep, mf_o1_coef), so that  contract discriminant >= 0  =>  W > 0: sign bit clear.
+// Precision.  Every f32 feature x is split into two f16 pieces x = p1 + p2 + e, |e| <= eta |x| + phi (eta = 2^-22; phi = 2^-25:
+// the floor once a piece is an f16 subnormal -- the instruction honours subnormal inputs, tools/ubench_mfma_f16_numerics.hip)
+// and three K slots hold the cross terms a1 b1, a1 b2, a2 b1 of a feature pair (a2 b2 <= 2^-22 |a b| is dropped), so every
+// product is exact in the f32 accumulator; the measured accumulation error of one MFMA is <= 2^-21.8 x max|term| (the budget
+// assumes beta = 2^-20 x (sum |terms| + |C|)).  Scales: lengths by the power of two s = mf_sc (|c_k| s <= 2^8; |o_k| s <= 2^13
+// for a ray that uses the filter: up to 32 x the scene's extent), so the linear features are 2 p_k s <= 2^15.5 and c_k s; the
+// quadratic features are 2 m d_i d_j (<= 2.002) and c_i c_j s^2 / 2 (<= 2^15); the two LARGE constants are split over two
+// scales so that no small piece lands in the f16 subnormal range:
+//     k' s^2  = 2^15 k1 + 2^4 k2                     against the ray-side constants (2^15, 2^4)  (0 for a ray that is not ok)
+//     (q^2 - oo') s^2 = 2^15 t1 + 2^4 (t2 + t3)       against the sphere-side constants (2^15, 2^4, 2^4)
+// 18 + 9 + 2 + 3 = 32 slots:
+//     slot  0-7   (MFMA 1, lanes 0-31)   xx xx xx yy yy yy zz zz        ray pieces (1 1 2 | 1 1 2 | 1 1)   sphere pieces (1 2 1 | 1 2 1 | 1 2)
+//     slot  8-15  (MFMA 1, lanes 32-63)  zz xy xy xy xz xz xz yz        (2 | 1 1 2 | 1 1 2 | 1)            (1 | 1 2 1 | 1 2 1 | 1)
+//     slot 16-23  (MFMA 2, lanes 0-31)   yz yz px px px py py py        (1 2 | 1 1 2 | 1 1 2)              (2 1 | 1 2 1 | 1 2 1)
+//     slot 24-31  (MFMA 2, lanes 32-63)  pz pz pz k k T T T             (1 1 2 | 2^15 2^4 | t1 t2 t3)      (1 2 1 | k1 k2 | 2^15 2^4 2^4)
+// Error budget in unscaled units, in multiples of 2^-22 (u = 2^-24 = 0.25, |d|^2 <= 1.001, S = (|o| + |c|)^2, |p| <= |o|):
+//     splits of the quadratic features (3.01 x sum |terms| <= 1.001 |c|^2)             3.02 |c|^2
+//     splits of the linear features (3.01 x 2 |p| |c|)                                 6.03 |o| |c|
+//     roundings of the features themselves (d_i d_j, c_i c_j, p_k)                      0.5 |c|^2 + 0.5 |o| |c|
+//     q computed in binary32 (3.01 u |o|) against 2 |hb| <= 2.001 (|o| + |c|)            3.01 (|o|^2 + |o| |c|)
+//     |o|^2, q^2 and the fma that forms q^2 - oo' in binary32                          1.3 |o|^2
+//     two MFMAs, beta x (sum |terms| + |C|)                     12.01 |c|^2 + 8.01 |o| |c| + 4.01 |o|^2 + 4 r^2 + 4 Gs
+//     contract discriminant vs exact arithmetic (binary32)   15 u |o - c|^2 + 4 u r^2   3.75 S + r^2
+//     inputs rounded from binary64 (hit_world_mfma<double>)                            1.5 S
+// With |o| |c| <= (|o|^2 + |c|^2) / 2 and S <= 2 |o|^2 + 2 |c|^2:  E <= 2^-22 (34.8 |c|^2 + 27.6 |o|^2 + 5 r^2) + floors,
+// floors <= phi_c (5.5 |o|_1 + |c|_1) + 1.4 phi_k, phi_c = 2^-25 / s (second pieces of the linear features; |p|_1 <= 2.74 |o|_1),
+// phi_k = 2^-20 / s^2 (the 2^4-scaled pieces of k' and q^2 - oo', the quadratic features' second pieces).  The margin separates:
+// the upload adds  Gs = 1.02 [(2 A_S + A_r)|c|^2 + A_r r^2 + 9 phi_c |c|_1 + 1.5 phi_k]  to k' (A_S = 32 x 2^-22 = 2^-17, A_r = 12 x
+// 2^-22: the round-2 constants, kept although this formulation needs only 35 / 28 / 5 of the 76 / 64 / 12 they provide -- no
+// error is amplified by a squaring any more) and the ray subtracts  oo' = |o|^2 (1 - 1.02 x 2^-16) - 9.18 phi_c |o|_1
+// (mf_oo_keep, mf_o1_coef), so that  contract discriminant >= 0  =>  W > 0: sign bit clear.
 // Rays that are not (nearly) unit (the reference does not renormalise dielectric reflections), not finite, or farther
-// than 2^14 / s from the origin take EVERY sphere as a candidate (all features 0, t1 = 60000); lanes without a ray take none
+// than 2^13 / s from the origin take EVERY sphere as a candidate (all features 0, t1 = 60000); lanes without a ray take none
 // (t1 = -60000).  Padding spheres carry k' s^2 = -2^30.
 // Lane layout of the instruction (A: row l & 31, k = 8 (l >> 5) + e; C/D: col l & 31, row (reg & 3) + 8 (reg >> 2) +
 // 4 (l >> 5)): lanes l and l + 32 hold the SAME 32 rays of a half wave and different spheres, so the candidates go to a
@@ -665,56 +677,56 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
                                               const WaveScratch &ws, unsigned lane, CLK &&clk = NoClock(),
                                               const MfmaCull *mc = nullptr, ORIG orig = ORIG()) {
     constexpr bool CULLED = !__is_same(ORIG, NoOrig);
-    // (lane group H = lane >> 5 supplies features 2H, 2H + 1)
     // ---- ray features (binary32) ----
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     const float s2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     const float oinf = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz));
     const bool ok = has_ray && s2 <= 1.0009f && oinf <= w.mf_o_max;                  // (false for NaN)
-    const float od = __builtin_fmaf(oz, dz, __builtin_fmaf(oy, dy, ox * dx));
+    const float q = __builtin_fmaf(oz, dz, __builtin_fmaf(oy, dy, ox * dx));          // d.o
     const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
     const float o1 = (__builtin_fabsf(ox) + __builtin_fabsf(oy)) + __builtin_fabsf(oz);
-    const float too = w.mf_sigma2 * __builtin_fmaf(oo, w.mf_oo_keep, -(w.mf_o1_coef * o1));       // oo' s^2
-    const float z = ok ? 1.0f : 0.0f;
-    const float f1[4] = {dx * z, dy * z, dz * z, -(od * w.mf_sc) * z};
-    const float f2[4] = {(ox + ox) * w.mf_sc * z, (oy + oy) * w.mf_sc * z, (oz + oz) * w.mf_sc * z, z};
-    // Lane (H, j) supplies its half of the K = 16 slots for ray j (first half wave: h = 0) / ray 32 + j (h = 1):
-    //   P1, slots 8H + e: features 2H and 2H + 1 with all four cross terms   A [a1 a1 a2 a2 | a1' a1' a2' a2']  B [b1 b2 b1 b2 | b1' b2' b1' b2']
-    //   P2, H = 0:  2ox.cx and 2oy.cy without the a2 b2 term
-    //               A [c1x c1x c2x c1y c1y c2y 0 0]         B [o1x o2x o1x o1y o2y o1y 0 0]
-    //       H = 1:  2oz.cz likewise; k' s^2 = 2^15 k1 + 2^4 k2 against the ray's constants (0 for a lane that is not ok);
-    //               -oo' s^2 = 2^15 t1 + 2^4 (t2 + t3) against the sphere side's constants (two scales keep the small
-    //               pieces out of the f16 subnormal range: a single 2^15 scale lost 2^-10 / s^2 of the margin and with it
-    //               7 pixels of the 320x180 golden image)
-    //               A [c1z c1z c2z k1 k2 2^15 2^4 2^4]      B [o1z o2z o1z 2^15 2^4 t1 t2 t3]
-    // so W = P1^2 + P2 needs no subtraction: one fma and one v_alignbit per (ray, sphere).
+    const float oop = __builtin_fmaf(oo, w.mf_oo_keep, -(w.mf_o1_coef * o1));         // oo' = |o|^2 - the ray's share of the margin
+    const float tq = w.mf_sigma2 * __builtin_fmaf(q, q, -oop);                        // (q^2 - oo') s^2
+    const float z = ok ? 1.0f : 0.0f, z2 = z + z, zs2 = z2 * w.mf_sc;
+    // p = o - q d, as 2 p_k s; the quadratic features 2 m d_i d_j
+    const float fp[3] = {__builtin_fmaf(-q, dx, ox) * zs2, __builtin_fmaf(-q, dy, oy) * zs2, __builtin_fmaf(-q, dz, oz) * zs2};
+    const float dx2 = dx * z2, dy2 = dy * z2, dz2 = dz * z2;
+    const float fq[6] = {dx2 * dx, dy2 * dy, dz2 * dz, (dx2 + dx2) * dy, (dx2 + dx2) * dz, (dy2 + dy2) * dz};
     // a lane that is not ok: all features 0 and t1 = +-60000 (exact in f16): W = +-2^15 x 60000 for EVERY sphere
-    const float tx = ok ? -too : (has_ray ? 60000.0f * 32768.0f : -60000.0f * 32768.0f);
-    // Every lane makes, for ITS ray, the operand words of both lane groups (H = 0: features 0, 1; H = 1: features 2, 3);
-    // one v_permlane32_swap per word then hands each lane group its words for both half waves:
+    const float tx = ok ? tq : (has_ray ? 60000.0f * 32768.0f : -60000.0f * 32768.0f);
+    // Lane (H, j) supplies slots 8H .. 8H + 7 of both MFMAs for ray j (first half wave: h = 0) / ray 32 + j (h = 1).  Every
+    // lane makes, for ITS ray, the operand words of both lane groups; one v_permlane32_swap per word then hands each lane
+    // group its words for both half waves:
     //     swap(X, Y):  X' = [X(0..31) | Y(0..31)],  Y' = [X(32..63) | Y(32..63)]
     // with X = the group-0 word and Y = the group-1 word of the lane's own ray, X' is the operand of the first half wave
     // (lane l < 32: its own ray's group-0 word; lane l >= 32: ray l - 32's group-1 word) and Y' that of the second.
-    const unsigned w10 = split_f16(f1[0]), w11 = split_f16(f1[1]), w12 = split_f16(f1[2]), w13 = split_f16(f1[3]);
-    const unsigned x0 = split_f16(f2[0]), x1 = split_f16(f2[1]), x2 = split_f16(f2[2]);
+    // With sw = (piece 1, piece 2) of a feature: (1, 1) = dup(sw), (2 of a, 1 of b) = alignbit(sw_b, sw_a, 16), (1, 2) = sw.
+    unsigned sq[6], sp[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sq[k] = split_f16(fq[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sp[k] = split_f16(fp[k]);
     const _Float16 t1 = (_Float16)(tx * (1.0f / 32768.0f));
     const float trem = tx - 32768.0f * (float)t1;                         // exact
     const unsigned x23 = split_f16(trem * (1.0f / 16.0f));               // (t2, t3)
     const unsigned sb = ok ? 0x7800u : 0u, ss = ok ? 0x4c00u : 0u;        // the ray's constants 2^15, 2^4 as f16 (0: not ok)
-    const unsigned g0[6] = {w10, w11, x0, (x0 & 0xffffu) | (x1 << 16), (x1 >> 16) | (x1 << 16), 0u};
-    //                      P1 a   P1 b  (o1x,o2x)  (o1x,o1y)              (o2y,o1y)              (0,0)
-    const unsigned g1[6] = {w12, w13, x2, (x2 & 0xffffu) | (sb << 16), ss | ((unsigned)__builtin_bit_cast(unsigned short, t1) << 16), x23};
-    //                      P1 a   P1 b  (o1z,o2z)  (o1z,2^15)             (2^4,t1)                                              (t2,t3)
-    unsigned h0[6], h1[6];
+    auto dup = [](unsigned v) { return __builtin_amdgcn_perm(v, v, 0x01000100u); };                 // (piece 1, piece 1)
+    auto cat = [](unsigned a, unsigned b) { return __builtin_amdgcn_alignbit(b, a, 16); };        // (piece 2 of a, piece 1 of b)
+    // words 0-3: MFMA 1 (slots 0-7 | 8-15), words 4-7: MFMA 2 (slots 16-23 | 24-31)
+    const unsigned g0[8] = {dup(sq[0]), cat(sq[0], sq[1]), sq[1], dup(sq[2]),                       // xx xx | xx yy | yy yy | zz zz
+                            sq[5], dup(sp[0]), cat(sp[0], sp[1]), sp[1]};                            // yz yz | px px | px py | py py
+    const unsigned g1[8] = {cat(sq[2], sq[3]), sq[3], dup(sq[4]), cat(sq[4], sq[5]),                // zz xy | xy xy | xz xz | xz yz
+                            dup(sp[2]), cat(sp[2], sb), ss | ((unsigned)__builtin_bit_cast(unsigned short, t1) << 16), x23};   // pz pz | pz k | k T | T T
+    unsigned h0[8], h1[8];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 8; ++k) {
         const auto sw = __builtin_amdgcn_permlane32_swap(g0[k], g1[k], false, false);
         h0[k] = sw[0]; h1[k] = sw[1];
     }
     rtw_h8 B1[2], B2[2];
     {
-        const uint4 q10 = {h0[0], h0[0], h0[1], h0[1]}, q11 = {h1[0], h1[0], h1[1], h1[1]};
-        const uint4 q20 = {h0[2], h0[3], h0[4], h0[5]}, q21 = {h1[2], h1[3], h1[4], h1[5]};
+        const uint4 q10 = {h0[0], h0[1], h0[2], h0[3]}, q11 = {h1[0], h1[1], h1[2], h1[3]};
+        const uint4 q20 = {h0[4], h0[5], h0[6], h0[7]}, q21 = {h1[4], h1[5], h1[6], h1[7]};
         B1[0] = __builtin_bit_cast(rtw_h8, q10); B1[1] = __builtin_bit_cast(rtw_h8, q11);
         B2[0] = __builtin_bit_cast(rtw_h8, q20); B2[1] = __builtin_bit_cast(rtw_h8, q21);
     }
@@ -764,24 +776,24 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         }
         unsigned mask = 0;
         const rtw_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        auto eval = [&](const rtw_f16v &P1, const rtw_f16v &P2) {
+        auto eval = [&](const rtw_f16v &Wv) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(__builtin_fmaf(P1[r], P1[r], P2[r])), 31);
+            for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]), 31);
         };
         {
-            const rtw_f16v P1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[0], zero, 0, 0, 0);
-            const rtw_f16v P2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[0], zero, 0, 0, 0);
-            eval(P1, P2);
+            rtw_f16v Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[0], zero, 0, 0, 0);
+            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[0], Wv, 0, 0, 0);
+            eval(Wv);
         }
         {
             // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
             // padding at the end), so only one set of A registers is live during the evaluation
-            const rtw_f16v P1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[1], zero, 0, 0, 0);
-            const rtw_f16v P2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[1], zero, 0, 0, 0);
+            rtw_f16v Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[1], zero, 0, 0, 0);
+            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[1], Wv, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];
             __builtin_amdgcn_sched_barrier(0);
-            eval(P1, P2);
+            eval(Wv);
         }
         clk.lap(2);
         unsigned m = ~mask;                               // bit 31 - b: half wave b >> 4, result register b & 15

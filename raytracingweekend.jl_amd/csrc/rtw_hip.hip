@@ -344,10 +344,11 @@ rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
     return C;
 }
 
-// Operands of pass 1 on the matrix pipe (rtw_device.hpp, hit_world_mfma): per block of 32 spheres two A operands of
-// v_mfma_f32_32x32x16_f16, P1 = [cx cy cz 1] s and P2 = [cx cy cz k'] (k' = r^2 - |c|^2 + the sphere's share Gs of the
-// error margin), every feature split into two f16 pieces.  Row i of the instruction holds sphere 16 ((i >> 2) & 1) +
-// (((i >> 3) << 2) | (i & 3)) of the block, so that result register r of lane (H, j) is sphere 16 H + r.
+// Operands of pass 1 on the matrix pipe (rtw_device.hpp, hit_world_mfma): per block of 32 spheres the two A operands of the
+// chained v_mfma_f32_32x32x16_f16 pair -- the sphere side of the K = 32 contraction
+//     [cx^2 cy^2 cz^2 cxcy cxcz cycz] s^2 / 2 | [cx cy cz] s | k' s^2 (k' = r^2 - |c|^2 + the sphere's share Gs of the error margin) | 1
+// every feature split into two f16 pieces, in the slot order documented there.  Row i of the instruction holds sphere
+// 16 ((i >> 2) & 1) + (((i >> 3) << 2) | (i & 3)) of the block, so that result register r of lane (H, j) is sphere 16 H + r.
 // `geom`: n entries; entries with r^2 < -1e29 are padding (never a candidate).  *ops_out / *blocks_out receive the device
 // array; the scale constants in `h` depend on the set of spheres only, so both orders of a scene get the same ones.
 template <typename T, typename V4>
@@ -366,19 +367,20 @@ int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, vo
     int ex = 0;
     (void)std::frexp(emax, &ex);                         // emax <= 2^ex
     if (ex > 40 || ex < -40) return 0;                   // outside what the scaled f16 pieces cover: VALU scan
-    // lengths x s: sphere coordinates and radii use 2^8 of the f16 range, ray origins may use 2^14 -- rays up to 64 x the
-    // scene's extent away still take the filter.  phi_c: a coordinate's second f16 piece is a subnormal below 2^-3
-    // (absolute error 2^-25 scaled); phi_k: the same floor for the 2^4-scaled pieces of k' and of the ray's oo'.
+    // lengths x s: sphere coordinates and radii use 2^8 of the f16 range (their products, halved: 2^15), ray origins may use
+    // 2^13 -- rays up to 32 x the scene's extent away still take the filter (2 |p_k| s <= 2 x 2.74 x 2^13 < 65504).
+    // phi_c: a coordinate's second f16 piece is a subnormal below 2^-3 (absolute error 2^-25 scaled); phi_k: the same floor for
+    // the 2^4-scaled pieces of k' and of the ray's constant and for the second pieces of the quadratic features.
     const double sc = std::ldexp(1.0, 8 - ex), sig2 = sc * sc;
     const double phi_c = std::ldexp(1.0, -25) / sc, phi_k = std::ldexp(1.0, -20) / sig2;
     const double A_S = std::ldexp(1.0, -17), A_r = std::ldexp(12.0, -22);
-    auto split = [](float x, unsigned &w0, unsigned &w1) {
-        const _Float16 p1 = (_Float16)x;
-        const _Float16 p2 = (_Float16)(x - (float)p1);
+    auto split = [](double x, unsigned &p1, unsigned &p2) {            // the f16 pieces of (float)x
+        const float xf = (float)x;
+        const _Float16 h1 = (_Float16)xf;
+        const _Float16 h2 = (_Float16)(xf - (float)h1);
         unsigned short b1, b2;
-        memcpy(&b1, &p1, 2); memcpy(&b2, &p2, 2);
-        w0 = (unsigned)b1 | ((unsigned)b1 << 16);         // (a1, a1)
-        w1 = (unsigned)b2 | ((unsigned)b2 << 16);         // (a2, a2)
+        memcpy(&b1, &h1, 2); memcpy(&b2, &h2, 2);
+        p1 = b1; p2 = b2;
     };
     const int nb = (n + 31) / 32;
     std::vector<uint4> ops((size_t)(nb + 1) * 128);
@@ -386,39 +388,39 @@ int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, vo
         for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 31, H = lane >> 5;
             const int sph = blk * 32 + 16 * ((i >> 2) & 1) + (((i >> 3) << 2) | (i & 3));
-            float f1[4] = {0, 0, 0, 0}, f2[3] = {0, 0, 0};
-            double kx = -1073741824.0;                                        // padding sphere: k' s^2 = -2^30: W = -2^30 - oo' s^2 < 0
+            double fq[6] = {0, 0, 0, 0, 0, 0}, fl[3] = {0, 0, 0};
+            double kx = -1073741824.0;                                        // padding sphere: k' s^2 = -2^30: W = -2^30 + (q^2 - oo') s^2 < 0
             if (live(sph)) {
                 const double cx = (double)(float)geom[sph].x, cy = (double)(float)geom[sph].y, cz = (double)(float)geom[sph].z;
                 const double r2 = (double)geom[sph].w, c2 = cx * cx + cy * cy + cz * cz;
-                const double Gs = 1.02 * ((2 * A_S + A_r) * c2 + A_r * r2 + 9 * phi_c * (std::fabs(cx) + std::fabs(cy) + std::fabs(cz)) + phi_k);
+                const double Gs = 1.02 * ((2 * A_S + A_r) * c2 + A_r * r2 + 9 * phi_c * (std::fabs(cx) + std::fabs(cy) + std::fabs(cz)) + 1.5 * phi_k);
                 kx = (r2 - c2 + Gs) * sig2;
-                f1[0] = f2[0] = (float)(cx * sc); f1[1] = f2[1] = (float)(cy * sc); f1[2] = f2[2] = (float)(cz * sc);
-                f1[3] = 1.0f;
+                const double hs = 0.5 * sig2;
+                fq[0] = cx * cx * hs; fq[1] = cy * cy * hs; fq[2] = cz * cz * hs; fq[3] = cx * cy * hs; fq[4] = cx * cz * hs; fq[5] = cy * cz * hs;
+                fl[0] = cx * sc; fl[1] = cy * sc; fl[2] = cz * sc;
             }
-            uint4 q1, q2;
-            split(f1[2 * H], q1.x, q1.y); split(f1[2 * H + 1], q1.z, q1.w);
-            // P2 (rtw_device.hpp): H = 0 [c1x c1x c2x c1y c1y c2y 0 0], H = 1 [c1z c1z c2z k1 k2 2^15 2^4 2^4]
+            unsigned q1[6], q2[6], l1[3], l2[3];
+            for (int k = 0; k < 6; ++k) split(fq[k], q1[k], q2[k]);
+            for (int k = 0; k < 3; ++k) split(fl[k], l1[k], l2[k]);
+            // k' s^2 = 2^15 k1 + 2^4 k2, the remainder rounded UP (a larger k' only widens the filter)
+            const _Float16 k1 = (_Float16)(float)(kx / 32768.0);
+            const double rem = (kx - 32768.0 * (double)(float)k1) / 16.0;
+            _Float16 k2 = (_Float16)(float)rem;
+            if ((double)(float)k2 < rem) { unsigned short b; memcpy(&b, &k2, 2); b = (unsigned short)((float)k2 >= 0.0f ? b + 1 : b - 1); memcpy(&k2, &b, 2); }
+            unsigned short kb1, kb2;
+            memcpy(&kb1, &k1, 2); memcpy(&kb2, &k2, 2);
+            auto pk = [](unsigned lo, unsigned hi) { return (lo & 0xffffu) | (hi << 16); };
+            // sphere pieces per slot (rtw_device.hpp): a feature's three slots are (1, 2, 1) against the ray's (1, 1, 2)
+            uint4 m1, m2;
             if (H == 0) {
-                unsigned a0, a1, b0, b1;
-                split(f2[0], a0, a1); split(f2[1], b0, b1);                    // (p1, p1), (p2, p2) of each feature
-                const unsigned p1a = a0 & 0xffffu, p2a = a1 & 0xffffu, p1b = b0 & 0xffffu, p2b = b1 & 0xffffu;
-                q2.x = p1a | (p1a << 16); q2.y = p2a | (p1b << 16); q2.z = p1b | (p2b << 16); q2.w = 0u;
+                m1 = uint4{pk(q1[0], q2[0]), pk(q1[0], q1[1]), pk(q2[1], q1[1]), pk(q1[2], q2[2])};      // xx xx | xx yy | yy yy | zz zz
+                m2 = uint4{pk(q2[5], q1[5]), pk(l1[0], l2[0]), pk(l1[0], l1[1]), pk(l2[1], l1[1])};      // yz yz | px px | px py | py py
             } else {
-                unsigned a0, a1;
-                split(f2[2], a0, a1);
-                const unsigned p1a = a0 & 0xffffu, p2a = a1 & 0xffffu;
-                // k' s^2 = 2^15 k1 + 2^4 k2, the remainder rounded UP (a larger k' only widens the filter)
-                const _Float16 k1 = (_Float16)(float)(kx / 32768.0);
-                const double rem = (kx - 32768.0 * (double)(float)k1) / 16.0;
-                _Float16 k2 = (_Float16)(float)rem;
-                if ((double)(float)k2 < rem) { unsigned short b; memcpy(&b, &k2, 2); b = (unsigned short)((float)k2 >= 0.0f ? b + 1 : b - 1); memcpy(&k2, &b, 2); }
-                unsigned short b1, b2;
-                memcpy(&b1, &k1, 2); memcpy(&b2, &k2, 2);
-                q2.x = p1a | (p1a << 16); q2.y = p2a | ((unsigned)b1 << 16); q2.z = (unsigned)b2 | (0x7800u << 16); q2.w = 0x4c004c00u;
+                m1 = uint4{pk(q1[2], q1[3]), pk(q2[3], q1[3]), pk(q1[4], q2[4]), pk(q1[4], q1[5])};      // zz xy | xy xy | xz xz | xz yz
+                m2 = uint4{pk(l1[2], l2[2]), pk(l1[2], kb1), pk(kb2, 0x7800u), 0x4c004c00u};             // pz pz | pz k | k T | T T
             }
-            ops[(size_t)blk * 128 + lane] = q1;
-            ops[(size_t)blk * 128 + 64 + lane] = q2;
+            ops[(size_t)blk * 128 + lane] = m1;
+            ops[(size_t)blk * 128 + 64 + lane] = m2;
         }
     HIP_TRY(hipMalloc(ops_out, ops.size() * sizeof(uint4)));
     HIP_TRY(hipMemcpy(*ops_out, ops.data(), ops.size() * sizeof(uint4), hipMemcpyHostToDevice));
@@ -430,7 +432,7 @@ int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, vo
     float coef = (float)(1.02 * 9 * phi_c);
     if ((double)coef < 1.02 * 9 * phi_c) coef = std::nextafter(coef, INFINITY);
     h->mf_o1_coef = coef;
-    h->mf_o_max = (float)(std::ldexp(1.0, 14) / sc);
+    h->mf_o_max = (float)(std::ldexp(1.0, 13) / sc);
     return 0;
 }
 
