@@ -2,30 +2,41 @@
 """bench.py -- Msamples/s of the hot path render -> ray_color -> hit/scatter on MI355X.
 
   python bench.py --gpus N --steps K --warmup W [--dtype f32|f64] [--width 1920|3840]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One "step" = one full render of the workload.  Default = BASELINE.json's headline, configs[2]:
 scene_random_spheres (reseed!(); 485 spheres), camera t_cam1, 1920x1080, 1000 spp, depth 50,
-Float32.  `--dtype f64 --width 3840` is the single-GPU share of configs[4] (3840x2160, Float64).
+Float32.  `--dtype f64 --width 3840` is the single-GPU share of configs[4] (3840x2160, Float64); the
+default run also times it (2 steps) and reports it as `f64_4k`.
 The scene is already resident in HBM when the timed region starts and the image is left in HBM
 on rank 0.  With N > 1 ranks the SAME image is tile-sharded over the ranks (strong scaling) and
 the zero-padded shard framebuffers are summed onto rank 0 with one RCCL reduce over xGMI inside
-the timed region.
+the timed region (`--collective gather`: each rank sends only its compact shard).
+
+N > 1: `python bench.py --gpus N ...` launched plainly (no WORLD_SIZE in the environment) starts its N ranks
+itself (torch.distributed.run, rendezvous on 127.0.0.1) and REFUSES to run when fewer than N devices are visible;
+launched by torch.distributed.run it checks WORLD_SIZE == N.  The line reports the world size the process group
+observed, the backend, every rank's device and mean kernel time, and the SHA-256 of the assembled frame
+(identical for every N: the image does not depend on the sharding).
+RTW_BENCH_ONE_DEVICE=1 (test aid for one-GPU boxes): every rank uses cuda:0 and the collective runs over
+gloo -- exercises the N > 1 control flow (sharding, collective, max-over-ranks timing), not RCCL itself.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline     -- roofline of the only kernel (rtw::trace_kernel): achieved = algorithmic flops =
                   counted ray-sphere tests x 17 flop (/root/reference/src/hit.jl:13-19)
                   divided by the kernel's HIP-event time on its launch stream.  The every-ray-
                   every-sphere part that this count measures runs as a conservative f16-split filter
-                  on the matrix pipe plus one FP32 fma + one alignbit per test, the
-                  exact contract arithmetic (FP32 / FP64) only on its candidates; a SIMD issues EITHER
-                  an MFMA or a VALU instruction (measured), so `peak` is the issue bound of that
-                  formulation: 4 MFMA cycles + 2 VALU x 2 cycles per 64 tests -> 334.2 algorithmic
-                  TFLOP/s.  `vs_fp32_vector_peak` relates the same achieved figure to the 157.3 TF
-                  vector peak that bounded the all-VALU scan of rounds 1-2 (it can exceed 1 now),
-                  `mfma_f16` gives the executed matrix-pipe flops against the 2.5 PF dense peak.
-                  `traffic` = HBM bytes per launch from the PMC passes (profiles/), plus the
-                  algorithmic HBM figure vs 8 TB/s.
+                  on the matrix pipe: ONE K = 32 contraction (two chained v_mfma_f32_32x32x16_f16) per
+                  32 spheres x 32 rays gives the whole filter value, the VALU adds one v_alignbit per
+                  test; the exact contract arithmetic (FP32 / FP64) runs only on the
+                  filter's candidates.  A SIMD issues EITHER an MFMA or a VALU instruction (measured:
+                  tools/ubench_mfma_pipe.hip), so `peak` is the issue bound of that formulation from the
+                  guide's cycle counts: 4 MFMA cycles + 1 VALU x 2 cycles per 64 tests -> 445.6
+                  algorithmic TFLOP/s.  `frac_fp32_vector` relates the same achieved figure to the
+                  157.3 TF vector peak of SURVEY 8(d) (it exceeds 1: the 17 flop are not executed as
+                  vector flops), `overlap_bound` to what a chip that overlapped MFMA and VALU issue
+                  would allow, `mfma_f16` gives the executed matrix-pipe flops against the 2.5 PF
+                  dense peak.  `traffic` = HBM bytes per launch from the PMC passes kept in
+                  profiles/ (static: not measured in this run), plus the algorithmic HBM figure.
   scan_valu    -- the same workload with RTW_FLAG_SCAN_VALU (the contract discriminant for every
                   sphere on the vector ALUs, the round-1/2 scan): same image, for comparison.
   cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
@@ -36,10 +47,14 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   end_to_end   -- one call of the host-buffer entry point rtw_render_* (scene upload, render,
                   D2H of the image: the PCIe-inclusive rate; never `value`).
   depth16      -- the same workload at the reference's own depth (src/ray_color.jl:14).
+  f64_4k       -- configs[4]'s single-GPU share (3840x2160, Float64), with its own roofline and cpu_baseline.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -52,12 +67,16 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
 # the guide lists no FP64 vector figure: AMD's MI355X datasheet gives 78.6 TFLOP/s (half the FP32 rate).
 VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
 MFMA_F16_PEAK_TFLOPS = 2500.0   # same guide: ~2.5 PF dense BF16/FP16 MFMA (2495 TF measured with 32x32x16)
-MFMA_FLOP_PER_TEST = 64         # two v_mfma_f32_32x32x16_f16 products per (ray, sphere): 2 x K=16 x 2 flop
+MFMA_FLOP_PER_TEST = 64         # two chained v_mfma_f32_32x32x16_f16 per 32 x 32 tests: 2 x K=16 x 2 flop per test
 HBM_PEAK_GBS = 8000.0
 FLOP_PER_TEST = 17              # 3 sub + 5 + 5 (dots) + mul/sub + mul/sub, src/hit.jl:13-19
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
+MFMA_CYCLES_PER_64_TESTS = 4.0  # 4 MFMAs x 32 cycles per block of 32 spheres x 64 rays (2048 tests)
+VALU_CYCLES_PER_64_TESTS = 2.0  # one v_alignbit_b32 per test = one wave instruction per 64 tests, 2 cycles/SIMD (guide: v_fma_f32 class)
+TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -67,7 +86,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the accelerated / end_to_end / depth16 legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the accelerated / scan_valu / end_to_end / depth16 / f64_4k legs")
     ap.add_argument("--group-cull", action="store_true", help="time the opt-in accelerated scan instead of the plain one")
     ap.add_argument("--scan-valu", action="store_true", help="time the all-VALU plain scan (RTW_FLAG_SCAN_VALU) instead of the matrix-pipe filter")
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per pixel (0 = library default rule)")
@@ -77,89 +96,252 @@ def main():
     ap.add_argument("--collective", choices=["reduce", "gather"], default="reduce",
                     help="N > 1: reduce = sum of zero-padded full frames onto rank 0 (BASELINE configs[3]); "
                          "gather = each rank sends only its compact tile-major shard (1/N of a frame)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.emulate_shard_of > 1 and (args.collective == "gather" or args.gpus > 1):
+        ap.error("--emulate-shard-of is a one-rank, reduce-layout analysis mode")
+    return args
 
+
+def self_spawn(args):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks under torch.distributed.run."""
+    import torch
+    one_device = os.environ.get("RTW_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (no CPU fallback)")
+    if have < args.gpus and not one_device:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible -- refusing to time fewer GPUs than asked for "
+                         f"(RTW_BENCH_ONE_DEVICE=1 emulates the {args.gpus}-rank control flow on one device)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, RTW_BENCH_SELF_SPAWNED="1")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class Ctx:
+    pass
+
+
+def setup(args):
     import numpy as np
     import torch
     import torch.distributed as dist
-
     import rtw_amd as R
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    c = Ctx()
+    c.np, c.torch, c.dist, c.R, c.args = np, torch, dist, R, args
+    c.rank = int(os.environ.get("RANK", "0"))
+    c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    c.world = int(os.environ.get("WORLD_SIZE", "1"))
+    if c.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={c.world}: the launcher must start exactly --gpus ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    # RTW_BENCH_ONE_DEVICE=1 (test aid for one-GPU boxes): every rank uses cuda:0 and the collective runs over gloo --
-    # exercises the N > 1 control flow of this script (sharding, collective, max-over-ranks timing), not RCCL itself
-    one_device = os.environ.get("RTW_BENCH_ONE_DEVICE") == "1"
-    if one_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
+    c.one_device = os.environ.get("RTW_BENCH_ONE_DEVICE") == "1"
+    if c.one_device:
+        c.local_rank = 0
+    elif c.local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {c.rank}: local rank {c.local_rank} has no device ({torch.cuda.device_count()} visible); "
+                         f"--gpus {args.gpus} needs {args.gpus} devices")
+    torch.cuda.set_device(c.local_rank)
+    c.dev = torch.device("cuda", c.local_rank)
+    c.backend = None
+    if c.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        c.backend = "gloo" if c.one_device else "nccl"              # "nccl" is RCCL on ROCm
+        if c.one_device:
+            dist.init_process_group("gloo", rank=c.rank, world_size=c.world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+            dist.init_process_group("nccl", rank=c.rank, world_size=c.world, device_id=c.dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    c.stream = torch.cuda.current_stream(c.dev)
+    return c
 
-    T = np.float64 if args.dtype == "f64" else np.float32
-    tT = torch.float64 if args.dtype == "f64" else torch.float32
-    jl = "Float64" if args.dtype == "f64" else "Float32"
-    W, spp, depth = args.width, args.spp, args.depth
-    H = R.image_height(W)
-    R.reseed()                                              # src/proto/proto.jl:198-199
-    scene = R.scene_random_spheres(elem_type=T)
-    cam = R.t_cam1(elem_type=T)
-    n_spheres = len(scene)
-    renderer = R.DeviceRenderer(scene, cam, device=local_rank)
-    fb = torch.empty(H * W * 3, dtype=tT, device=dev)
-    stream = torch.cuda.current_stream(dev)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+def fence(c):
+    if c.world > 1:
+        c.dist.barrier()
+    c.torch.cuda.synchronize(c.dev)
 
-    def timed(n_steps, n_warm, *, cull, depth_, record=None, valu=args.scan_valu):
-        """W untimed + K timed steps bracketed by barrier + synchronize; returns max-over-ranks seconds."""
+
+class Workload:
+    """scene_random_spheres / t_cam1 at one precision and size, resident on this rank's device."""
+
+    def __init__(self, c, dtype, W, spp, depth):
+        np, torch, R = c.np, c.torch, c.R
+        self.c, self.dtype, self.W, self.spp, self.depth = c, dtype, W, spp, depth
+        self.T = np.float64 if dtype == "f64" else np.float32
+        self.tT = torch.float64 if dtype == "f64" else torch.float32
+        self.jl = "Float64" if dtype == "f64" else "Float32"
+        self.H = R.image_height(W)
+        R.reseed()                                              # src/proto/proto.jl:198-199
+        self.scene = R.scene_random_spheres(elem_type=self.T)
+        self.cam = R.t_cam1(elem_type=self.T)
+        self.n_spheres = len(self.scene)
+        self.renderer = R.DeviceRenderer(self.scene, self.cam, device=c.local_rank)
+        n = self.H * W * 3
+        if c.args.collective == "gather":                       # compact shards of ragged frames can exceed H*W*3 (whole tiles)
+            n = max(n, R.compact_elems(W, 0, c.world))
+        self.fb = torch.empty(n, dtype=self.tT, device=c.dev)
+        self.frame = None
+
+    def close(self):
+        self.renderer.close()
+        self.fb = None
+
+    def timed(self, n_steps, n_warm, *, cull, depth, record=None, valu=False):
+        """n_warm untimed + n_steps timed steps bracketed by barrier + synchronize; returns max-over-ranks seconds."""
+        c, a = self.c, self.c.args
+
         def step(rec):
             def shard(idx, cnt):
-                if args.emulate_shard_of > 1:
-                    idx, cnt = 0, args.emulate_shard_of
-                renderer.render_into(fb.data_ptr(), W, spp, depth=depth_, seed=1, n_chunks=args.chunks, shard_index=idx,
-                                     shard_count=cnt, stream=stream.cuda_stream, group_cull=cull,
-                                     compact=args.collective == "gather", scan_valu=valu and not cull)
-                return fb
-            R.render_sharded(shard, W, mode=args.collective)    # renders this rank's tiles, ONE collective onto rank 0
+                if a.emulate_shard_of > 1:
+                    idx, cnt = 0, a.emulate_shard_of
+                self.renderer.render_into(self.fb.data_ptr(), self.W, self.spp, depth=depth, seed=1, n_chunks=a.chunks, shard_index=idx,
+                                          shard_count=cnt, stream=c.stream.cuda_stream, group_cull=cull,
+                                          compact=a.collective == "gather", scan_valu=valu and not cull, n_elems=self.fb.numel())
+                return self.fb
+            self.frame = c.R.render_sharded(shard, self.W, mode=a.collective)    # this rank's tiles, ONE collective onto rank 0
             if rec is not None:
-                rec.append(renderer.stats())                # waits for this rank's kernel (HIP events on `stream`)
+                rec.append(self.renderer.stats())               # waits for this rank's kernel (HIP events on `stream`)
         for _ in range(n_warm):
             step(None)
-        fence()
+        fence(c)
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step(record)
-        fence()
+        fence(c)
         dt = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if c.world > 1:
+            tmax = c.torch.tensor([dt], dtype=c.torch.float64, device=c.dev)
+            c.dist.all_reduce(tmax, op=c.dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt
 
+    def frame_sha256(self):
+        """SHA-256 of the assembled H x W x 3 frame of the last step (rank 0; outside every timed region)."""
+        n = self.H * self.W * 3
+        host = self.frame.reshape(-1)[:n].cpu().numpy()
+        return hashlib.sha256(host.tobytes()).hexdigest()
+
+
+def roofline_of(wl, k_s, tests_per_launch, seg_per_sample, *, cull, valu, world, shard_div):
+    args = wl.c.args
+    W, H, spp, depth = wl.W, wl.H, wl.spp, wl.depth
+    issue_peak = N_SIMD * CLOCK_HZ / (MFMA_CYCLES_PER_64_TESTS + VALU_CYCLES_PER_64_TESTS) * 64 * FLOP_PER_TEST / 1e12
+    overlap_peak = N_SIMD * CLOCK_HZ / max(MFMA_CYCLES_PER_64_TESTS, VALU_CYCLES_PER_64_TESTS) * 64 * FLOP_PER_TEST / 1e12
+    peak = issue_peak if not valu else VALU_PEAK_TFLOPS[wl.dtype]
+    achieved = tests_per_launch * FLOP_PER_TEST / k_s / 1e12
+    mfma_tflops = tests_per_launch * MFMA_FLOP_PER_TEST / k_s / 1e12
+    esize = 8 if wl.dtype == "f64" else 4
+    alg_bytes = W * H * 3 * esize / world / shard_div + wl.n_spheres * 12 * esize   # framebuffer write + one scene read
+    # HBM bytes per launch from the PMC passes kept under profiles/ (separate --pmc runs of this same command): static,
+    # valid for the exact workload they were taken on -- rocprofv3 counters cannot be read from inside this process
+    traffic = traffic_src = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+        key = f"{wl.dtype}_{W}x{H}_{spp}spp_d{depth}_{'cull' if cull else ('valu' if valu else 'plain')}"
+        if world == 1 and shard_div == 1 and key in tr:
+            traffic, traffic_src = tr[key]["hbm_bytes_per_launch"], tr[key].get("source")
+    except Exception:
+        pass
+    matrix = not (cull or valu)
+    return {
+        "bound": ("valu_" + ("fp64" if wl.dtype == "f64" else "fp32")) if valu else "mfma",
+        "bound_detail": None if not matrix else "SIMD issue time shared by v_mfma_f32_32x32x16_f16 (32 cycles each) and VALU (2 cycles each): no overlap on gfx950",
+        "kernel": f"rtw::trace_kernel<{'double' if wl.dtype == 'f64' else 'float'}>",
+        "achieved": None if cull else round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+        "frac": None if cull else round(achieved / peak, 4),
+        "peak_derivation": None if not matrix else
+            "1024 SIMDs x 2.4 GHz / (4 MFMA + 2 VALU cycles per 64 tests) x 64 tests x 17 algorithmic flop (cycle counts: MI355X_MICROARCH.md); "
+            "rounds 1-2 used 157.3 (all-VALU scan) and 334.2 (two products + fma + alignbit: 4 + 4 cycles)",
+        "frac_fp32_vector": None if cull else round(achieved / VALU_PEAK_TFLOPS["f32"], 4),
+        "fp32_vector_peak": VALU_PEAK_TFLOPS["f32"],
+        "overlap_bound": None if not matrix else {"peak": round(overlap_peak, 1), "frac": round(achieved / overlap_peak, 4),
+                                                   "note": "if MFMA and VALU issue overlapped perfectly (they do not on this chip)"},
+        "traffic": traffic, "traffic_static": True,
+        "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this command; read from " + TRAFFIC_FILE + ")",
+        "traffic_source": traffic_src,
+        "kernel_ms": round(k_s * 1e3, 3), "tests_per_launch": int(tests_per_launch),
+        "flop_per_test": FLOP_PER_TEST, "segments_per_sample": round(seg_per_sample, 4),
+        "mfma_f16": None if not matrix else {"executed_flop_per_test": MFMA_FLOP_PER_TEST, "achieved": round(mfma_tflops, 1),
+                                              "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_tflops / MFMA_F16_PEAK_TFLOPS, 4)},
+        "valu": None if not matrix else {"instructions_per_test": 1, "what": "v_alignbit_b32 (sign bit of the filter value into the candidate mask)"},
+        "note": "achieved = counted ray-sphere tests x 17 algorithmic flop / kernel time.  Every sphere is tested against every ray segment, but "
+                "pass 1 of the scan is a conservative FILTER: D = (d.c)^2 + 2 p.c + (q^2 - |o|^2) + (r^2 - |c|^2) is bilinear in (ray features) x "
+                "(sphere features), so one K = 32 contraction over f16-split features (two chained v_mfma_f32_32x32x16_f16) evaluates 32 spheres x 32 "
+                "rays and the VALU adds one alignbit per test (rigorous margin, DESIGN.md 6.1); the exact contract arithmetic (17 flop, FP32 or FP64) "
+                "runs only on the filter's candidates.  `scan_valu` is the same workload with every test on the vector ALUs."
+                if matrix else
+                ("all-VALU plain scan (RTW_FLAG_SCAN_VALU): 11 instructions per test (Float32) / 13 binary32 filter instructions (Float64)"
+                 if valu else "group-cull mode: tests are skipped, no roofline fraction"),
+        "hbm": {"algorithmic_bytes": int(alg_bytes), "achieved_GBs": round(alg_bytes / k_s / 1e9, 4),
+                "peak_GBs": HBM_PEAK_GBS, "frac": round(alg_bytes / k_s / 1e9 / HBM_PEAK_GBS, 8)},
+    }
+
+
+def cpu_legs(wl, seconds):
+    """The CPU oracle on this box's host cores, bounded sample: [16-thread leg (if the box has 16), all-threads leg]."""
+    import rtw_oracle as O
+    O.build()
+    R = wl.c.R
+    flat = R.flatten_scene(wl.scene, wl.T)
+    threads = O.max_threads()
+
+    def leg(nthr):
+        t = time.perf_counter()
+        O.render(flat, wl.cam, wl.W, wl.H, 1, T=wl.T, max_depth=wl.depth, seed=1, n_chunks=1, omp_threads=nthr)
+        t1 = time.perf_counter() - t
+        s_spp = int(max(1, min(64, round(seconds / max(t1, 1e-3)))))
+        t = time.perf_counter()
+        O.render(flat, wl.cam, wl.W, wl.H, s_spp, T=wl.T, max_depth=wl.depth, seed=1, omp_threads=nthr)
+        tc = time.perf_counter() - t
+        return {"value": round(wl.W * wl.H * s_spp / tc / 1e6, 4), "unit": "Msamples/s", "cores": nthr, "kind": "port",
+                "sample": f"same scene/camera/{wl.W}x{wl.H}/depth {wl.depth}/{wl.jl}, {s_spp} spp ({tc:.1f} s), oracle/ C port with OpenMP; "
+                          f"the Julia reference cannot run here (no julia in the image)"}
+    # the GPU boxes are shared hosts (2 x EPYC 9575F, cgroup-limited): all-threads runs are often SLOWER than
+    # 16 threads there.  Both legs are reported; `cpu_baseline` is the faster one (the fairer baseline).
+    legs = [leg(16)] if threads >= 16 else []
+    legs.append(leg(threads))
+    return legs, (legs[0] if threads >= 16 else None)
+
+
+def cfg_name(dtype, W, spp, depth, world):
+    return {("f32", 1920, 1000, 50): "BASELINE.json configs[2]" if world == 1 else "BASELINE.json configs[3]",
+            ("f64", 3840, 1000, 50): "BASELINE.json configs[4]" + (", one GPU" if world == 1 else "")}.get((dtype, W, spp, depth), "not a BASELINE config")
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)                                        # does not return
+    c = setup(args)
+    np, torch, dist, R = c.np, c.torch, c.dist, c.R
+    rank, world = c.rank, c.world
+
+    wl = Workload(c, args.dtype, args.width, args.spp, args.depth)
+    W, H, spp, depth = wl.W, wl.H, wl.spp, wl.depth
     stats = []
-    dt = timed(args.steps, args.warmup, cull=args.group_cull, depth_=depth, record=stats)
+    dt = wl.timed(args.steps, args.warmup, cull=args.group_cull, depth=depth, record=stats, valu=args.scan_valu)
+    sha = wl.frame_sha256() if rank == 0 else None
     kernel_ms = [s["kernel_ms"] for s in stats]
     tests = [s["sphere_tests"] for s in stats]
     segments = [s["segments"] for s in stats]
+    per_rank = None
     if world > 1:
-        agg = torch.tensor([sum(tests), sum(segments)], dtype=torch.float64, device=dev)
+        agg = torch.tensor([sum(tests), sum(segments)], dtype=torch.float64, device=c.dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         all_segments = float(agg[1])
+        mine = torch.tensor([sum(kernel_ms) / len(kernel_ms), float(c.local_rank)], dtype=torch.float64, device=c.dev)
+        allk = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allk, mine)
+        per_rank = [{"rank": r, "device": int(t[1].item()), "kernel_ms": round(float(t[0].item()), 3)} for r, t in enumerate(allk)]
     else:
         all_segments = float(sum(segments))
 
@@ -168,140 +350,103 @@ def main():
     value = samples_per_step * args.steps / dt / 1e6
 
     extras = not args.no_extras and args.emulate_shard_of <= 1
-    accel = depth16 = None
+    accel = depth16 = scan_valu = end_to_end = f64_4k = None
     if extras and not args.group_cull:
         # the opt-in accelerated scan (RTW_FLAG_GROUP_CULL, bit-identical image), timed the same way, reported
         # separately: `value` stays the reference's plain linear scan so that the roofline figure means what it says
-        dta = timed(args.steps, 1, cull=True, depth_=depth)
+        dta = wl.timed(args.steps, 1, cull=True, depth=depth)
         accel = {"mode": "RTW_FLAG_GROUP_CULL (kd-sorted blocks of 32 spheres skipped when no ray of the wave can touch the block's grown box, in front of the matrix-pipe filter; same image bit for bit)",
                  "value": round(samples_per_step * args.steps / dta / 1e6, 2), "unit": "Msamples/s",
-                 "ms_per_step": round(dta / args.steps * 1e3, 3)}
-    scan_valu = None
+                 "ms_per_step": round(dta / args.steps * 1e3, 3), "frame_sha256_equal": (wl.frame_sha256() == sha) if rank == 0 else None}
     if extras and not args.group_cull and not args.scan_valu:
-        dtv = timed(1, 0, cull=False, depth_=depth, valu=True)
+        dtv = wl.timed(1, 0, cull=False, depth=depth, valu=True)
         scan_valu = {"mode": "RTW_FLAG_SCAN_VALU (contract discriminant for every sphere on the vector ALUs; same image bit for bit)",
-                     "value": round(samples_per_step / dtv / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtv * 1e3, 3)}
+                     "value": round(samples_per_step / dtv / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtv * 1e3, 3),
+                     "frame_sha256_equal": (wl.frame_sha256() == sha) if rank == 0 else None}
     if extras and depth != 16:
         st16 = []
-        dt16 = timed(1, 0, cull=args.group_cull, depth_=16, record=st16)
+        dt16 = wl.timed(1, 0, cull=args.group_cull, depth=16, record=st16, valu=args.scan_valu)
         depth16 = {"value": round(samples_per_step / dt16 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt16 * 1e3, 3),
                    "segments_per_sample": round(st16[0]["segments"] * world / samples_per_step, 4) if world == 1 else None,
                    "note": "same workload at depth 16, the reference's only depth (src/ray_color.jl:14)"}
-
-    end_to_end = None
-    if extras and world == 1 and rank == 0:
-        # host-buffer entry point, what the Julia ccall binds: scene upload + render + image D2H, blocking
-        t = time.perf_counter()
-        R.render(scene, cam, W, spp, depth=depth, seed=1, n_chunks=args.chunks, device=local_rank, group_cull=args.group_cull,
-                 scan_valu=args.scan_valu)
-        te = time.perf_counter() - t
+    if extras and world == 1:
+        # host-buffer entry point, what the Julia ccall binds: scene upload + render + image D2H, blocking.
+        # Twice: the first call builds the library's per-device context (scene, stream, device image, pinned staging), the
+        # second one reuses it -- what a caller that renders frame after frame pays.
+        e2e = []
+        for _ in range(2):
+            t = time.perf_counter()
+            R.render(wl.scene, wl.cam, W, spp, depth=depth, seed=1, n_chunks=args.chunks, device=c.local_rank, group_cull=args.group_cull,
+                     scan_valu=args.scan_valu)
+            e2e.append((time.perf_counter() - t, R.last_stats()["kernel_ms"]))
+        te, tk = e2e[1]
         end_to_end = {"value": round(W * H * spp / te / 1e6, 2), "unit": "Msamples/s", "ms": round(te * 1e3, 3),
-                      "kernel_ms": round(R.last_stats()["kernel_ms"], 3),
+                      "kernel_ms": round(tk, 3), "overhead_ms": round(te * 1e3 - tk, 3),
+                      "first_call_ms": round(e2e[0][0] * 1e3, 3), "first_call_kernel_ms": round(e2e[0][1], 3),
                       "note": "rtw_render_* on host buffers: H2D scene, render, D2H image (PCIe-inclusive); never `value`"}
 
+    line = None
     if rank == 0:
         # the only kernel = trace_kernel.  Per launch (this rank's shard): algorithmic flops =
         # sphere tests x 17; duration = mean HIP-event time on the launch stream.
         k_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
-        tests_per_launch = sum(tests) / len(tests)
-        # issue bound of the matrix-pipe formulation: per 64 tests (one sphere x one wave) 4 v_mfma_f32_32x32x16_f16 per 32 spheres x
-        # 32 cycles (MI355X_MICROARCH.md: 32 cyc/SIMD) = 4 cycles, + 2 VALU x 2 cycles (v_fma_f32: 2 cyc/SIMD) = 4 cycles; MFMA and
-        # VALU issue do not overlap on a SIMD (tools/ubench_mfma_overlap.hip, profiles/r02_ubench_mfma.txt)
-        issue_peak = 1024 * 2.4e9 / 8 * 64 * FLOP_PER_TEST / 1e12
-        peak = issue_peak if not args.scan_valu else VALU_PEAK_TFLOPS[args.dtype]
-        achieved_tflops = tests_per_launch * FLOP_PER_TEST / k_s / 1e12
-        mfma_tflops = tests_per_launch * MFMA_FLOP_PER_TEST / k_s / 1e12
-        esize = 8 if args.dtype == "f64" else 4
-        alg_bytes = W * H * 3 * esize / world / shard_div + n_spheres * 12 * esize   # framebuffer write + one scene read
-        # HBM bytes per launch from the PMC passes (profiles/), valid for the exact workload they were taken on
-        traffic = traffic_src = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
-            key = f"{args.dtype}_{W}x{H}_{spp}spp_d{depth}_{'cull' if args.group_cull else ('valu' if args.scan_valu else 'plain')}"
-            if world == 1 and shard_div == 1 and key in tr:
-                traffic, traffic_src = tr[key]["hbm_bytes_per_launch"], tr[key].get("source")
-        except Exception:
-            pass
-        if args.group_cull:
-            achieved_tflops = float("nan")          # the cull mode skips tests: a fraction of never-executed tests would be meaningless
-        matrix = not (args.group_cull or args.scan_valu)
-        roofline = {
-            "bound": ("valu_" + ("fp64" if args.dtype == "f64" else "fp32")) if args.scan_valu else "mfma",
-            "bound_detail": None if not matrix else "SIMD issue time shared by v_mfma_f32_32x32x16_f16 (32 cycles each) and FP32 VALU (2 cycles each)",
-            "kernel": f"rtw::trace_kernel<{'double' if args.dtype == 'f64' else 'float'}>",
-            "achieved": None if args.group_cull else round(achieved_tflops, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": None if args.group_cull else round(achieved_tflops / peak, 4),
-            "peak_derivation": None if not matrix else
-                "1024 SIMDs x 2.4 GHz / (4 MFMA + 4 VALU cycles per 64 tests) x 64 tests x 17 algorithmic flop (cycle counts: MI355X_MICROARCH.md)",
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
-            "traffic_source": traffic_src,
-            "kernel_ms": round(k_s * 1e3, 3), "tests_per_launch": int(tests_per_launch),
-            "flop_per_test": FLOP_PER_TEST, "segments_per_sample": round(all_segments / (samples_per_step * args.steps), 4),
-            "vs_fp32_vector_peak": None if not matrix else {"peak": VALU_PEAK_TFLOPS["f32"], "frac": round(achieved_tflops / VALU_PEAK_TFLOPS["f32"], 4),
-                                                             "note": "the bound of the all-VALU scan (rounds 1-2: 0.486 / 0.50); the algorithmic flops are "
-                                                                     "no longer executed as vector flops, so this can exceed 1"},
-            "mfma_f16": None if not matrix else {"executed_flop_per_test": MFMA_FLOP_PER_TEST, "achieved": round(mfma_tflops, 1),
-                                                  "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_tflops / MFMA_F16_PEAK_TFLOPS, 4)},
-            "valu_fp32": None if not matrix else {"instructions_per_test": 2, "what": "v_fma_f32 (hb^2 + m) + v_alignbit_b32 (sign bit into the candidate mask)"},
-            "note": "achieved = counted ray-sphere tests x 17 algorithmic flop / kernel time.  Every sphere is tested against every ray segment, but "
-                    "pass 1 of the scan is a conservative FILTER: the discriminant is bilinear in (ray features) x (sphere features), so two "
-                    "v_mfma_f32_32x32x16_f16 over f16-split features evaluate 32 spheres x 32 rays and the VALU adds one fma + one alignbit per test "
-                    "(rigorous margin, DESIGN.md 6.1); the exact contract arithmetic (17 flop, FP32 or FP64) runs only on the filter's candidates.  "
-                    "`scan_valu` is the same workload with every test on the vector ALUs."
-                    if matrix else
-                    ("all-VALU plain scan (RTW_FLAG_SCAN_VALU): 11 instructions per test (Float32) / 13 binary32 filter instructions (Float64)"
-                     if args.scan_valu else "group-cull mode: tests are skipped, no roofline fraction"),
-            "hbm": {"algorithmic_bytes": int(alg_bytes), "achieved_GBs": round(alg_bytes / k_s / 1e9, 4),
-                    "peak_GBs": HBM_PEAK_GBS, "frac": round(alg_bytes / k_s / 1e9 / HBM_PEAK_GBS, 8)},
-        }
+        roofline = roofline_of(wl, k_s, sum(tests) / len(tests), all_segments / (samples_per_step * args.steps),
+                               cull=args.group_cull, valu=args.scan_valu, world=world, shard_div=shard_div)
         cpu = cpu16 = None
         legs = []
         if world == 1 and not args.no_cpu_baseline:
-            import rtw_oracle as O
-            O.build()
-            flat = R.flatten_scene(scene, T)
-            threads = O.max_threads()
-
-            def cpu_leg(nthr):
-                t = time.perf_counter()
-                O.render(flat, cam, W, H, 1, T=T, max_depth=depth, seed=1, n_chunks=1, omp_threads=nthr)
-                t1 = time.perf_counter() - t
-                s_spp = int(max(1, min(64, round(args.cpu_seconds / max(t1, 1e-3)))))
-                t = time.perf_counter()
-                O.render(flat, cam, W, H, s_spp, T=T, max_depth=depth, seed=1, omp_threads=nthr)
-                tc = time.perf_counter() - t
-                return {"value": round(W * H * s_spp / tc / 1e6, 4), "unit": "Msamples/s", "cores": nthr, "kind": "port",
-                        "sample": f"same scene/camera/{W}x{H}/depth {depth}/{jl}, {s_spp} spp ({tc:.1f} s), oracle/ C port with OpenMP; "
-                                  f"the Julia reference cannot run here (no julia in the image)"}
-            # the GPU boxes are shared hosts (2 x EPYC 9575F, cgroup-limited): all-threads runs are often SLOWER than
-            # 16 threads there.  Both legs are reported; `cpu_baseline` is the faster one (the fairer baseline).
-            legs = [cpu_leg(16)] if threads >= 16 else []
-            legs.append(cpu_leg(threads))
-            cpu16 = legs[0] if threads >= 16 else None
+            legs, cpu16 = cpu_legs(wl, args.cpu_seconds)
             cpu = max(legs, key=lambda d: d["value"])
-        cfg_name = {("f32", 1920, 1000, 50): "BASELINE.json configs[2]" if world == 1 else "BASELINE.json configs[3]",
-                    ("f64", 3840, 1000, 50): "BASELINE.json configs[4]" + (", one GPU" if world == 1 else "")}.get(
-            (args.dtype, W, spp, depth), "not a BASELINE config")
         line = {
             "metric": f"Msamples/s (pixels x spp) on scene_random_spheres {W}x{H}",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"scene_random_spheres ({n_spheres} spheres, reseed!() seed 1), t_cam1, {W}x{H}, {spp} spp, "
-                                   f"depth {depth}, {jl} ({cfg_name})",
+            "config": {"workload": f"scene_random_spheres ({wl.n_spheres} spheres, reseed!() seed 1), t_cam1, {W}x{H}, {spp} spp, "
+                                   f"depth {depth}, {wl.jl} ({cfg_name(args.dtype, W, spp, depth, world)})",
                        "scan": "group_cull (opt-in)" if args.group_cull else
                                ("plain linear scan over all spheres, all on the VALU (RTW_FLAG_SCAN_VALU)" if args.scan_valu else
                                 "plain linear scan over all spheres (reference algorithm): matrix-pipe filter + exact test of its candidates"),
                        "parallelism": f"tile-sharded x{world}" + (f" + 1 RCCL {args.collective}" if world > 1 else ""),
                        "rng": f"Xoroshiro128+ per (pixel, chunk), {stats[0]['n_chunks']} chunks/pixel; exact fixed-point pixel accumulation"},
+            "world_size_observed": dist.get_world_size() if world > 1 else 1, "backend": c.backend,
+            "launched_by": "bench.py (self-spawned torch.distributed.run)" if os.environ.get("RTW_BENCH_SELF_SPAWNED") == "1" else
+                           ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "python"),
+            "one_device_emulation": c.one_device if world > 1 else None,
+            "per_rank": per_rank, "frame_sha256": sha,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_16t": cpu16,
-            "cpu_baseline_all_threads": (legs[-1] if world == 1 and not args.no_cpu_baseline else None), "accelerated": accel,
+            "cpu_baseline_all_threads": (legs[-1] if legs else None), "accelerated": accel,
             "scan_valu": scan_valu, "end_to_end": end_to_end, "depth16": depth16,
         }
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
         if cpu16:
             line["gpu_over_cpu_16t"] = round(value / cpu16["value"], 1)
+    wl.close()
+
+    # configs[4]'s single-GPU share, in the default run only (the headline stays configs[2])
+    if extras and world == 1 and (args.dtype, W, spp, depth) == ("f32", 1920, 1000, 50) and not (args.group_cull or args.scan_valu):
+        w4 = Workload(c, "f64", 3840, 1000, 50)
+        st4 = []
+        n4 = 2
+        dt4 = w4.timed(n4, 1, cull=False, depth=50, record=st4)
+        k4 = sum(s["kernel_ms"] for s in st4) / len(st4) / 1e3
+        samples4 = w4.W * w4.H * 1000
+        f64_4k = {"config": {"workload": f"scene_random_spheres ({w4.n_spheres} spheres), t_cam1, 3840x2160, 1000 spp, depth 50, Float64 "
+                                         f"({cfg_name('f64', 3840, 1000, 50, 1)})"},
+                  "value": round(samples4 * n4 / dt4 / 1e6, 2), "unit": "Msamples/s", "steps": n4, "warmup": 1, "ms_per_step": round(dt4 / n4 * 1e3, 3),
+                  "dtype": "f64", "frame_sha256": w4.frame_sha256(),
+                  "roofline": roofline_of(w4, k4, sum(s["sphere_tests"] for s in st4) / len(st4),
+                                          sum(s["segments"] for s in st4) / (samples4 * n4), cull=False, valu=False, world=1, shard_div=1)}
+        f64_4k["roofline"]["note_f64"] = ("pass 1 is the same binary32/f16 matrix-pipe filter in both precisions; FP64 arithmetic (two issue slots per "
+                                          "instruction) only in pass 2 and shading, so the same issue bound applies")
+        if not args.no_cpu_baseline:
+            legs4, _ = cpu_legs(w4, min(args.cpu_seconds, 8.0))
+            f64_4k["cpu_baseline"] = max(legs4, key=lambda d: d["value"])
+            f64_4k["gpu_over_cpu"] = round(f64_4k["value"] / f64_4k["cpu_baseline"]["value"], 1)
+        w4.close()
+    if rank == 0:
+        line["f64_4k"] = f64_4k
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

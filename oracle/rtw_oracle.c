@@ -75,6 +75,7 @@ static inline double rng_f64(orng *r) {
     return d - 1.0;
 }
 
+uint64_t rtwo_splitmix64(uint64_t *state) { return splitmix64(state); }
 void rtwo_rng_seed(uint64_t seed, uint64_t state[2]) {
     orng r; rng_seed_int(seed, &r); state[0] = r.x; state[1] = r.y;
 }

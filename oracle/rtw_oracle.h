@@ -108,7 +108,12 @@ int rtwo_render_f32(const rtwo_scene_f32 *, const rtwo_camera_f32 *, const rtwo_
 int rtwo_render_f64(const rtwo_scene_f64 *, const rtwo_camera_f64 *, const rtwo_params *,
                     double *out, rtwo_stats *stats);
 
+/* radiances of all spp samples of pixel (i, j) (1-based) in PIXEL_STREAM mode, sample order: out[3 s + channel] */
+int rtwo_pixel_samples_f32(const rtwo_scene_f32 *, const rtwo_camera_f32 *, const rtwo_params *, int i, int j, double *out);
+int rtwo_pixel_samples_f64(const rtwo_scene_f64 *, const rtwo_camera_f64 *, const rtwo_params *, int i, int j, double *out);
+
 /* ---- RNG (src/init.jl:2-12, src/rand.jl:2-13; RandomNumbers.jl 1.5.3 restated) ---------- */
+uint64_t rtwo_splitmix64(uint64_t *state);                            /* one SplitMix64 step: state += golden gamma, returns the mixed output */
 void rtwo_rng_seed(uint64_t seed, uint64_t state[2]);                 /* Xoroshiro128Plus(seed) */
 void rtwo_rng_stream(uint64_t seed, uint64_t pixel, uint64_t chunk, uint64_t state[2]);
 uint64_t rtwo_rng_next(uint64_t state[2]);

@@ -146,6 +146,25 @@ def render(flat_scene, cam, width, height, spp, *, T=np.float32, max_depth=16, s
     return img, {k: getattr(st, k) for k, _ in st._fields_}
 
 
+def pixel_samples(flat_scene, cam, width, height, spp, i, j, *, T=np.float32, max_depth=16, seed=1, n_chunks=None,
+                  product_order=PRODUCT_FORWARD):
+    """Radiance of every sample of pixel (i, j) (1-based) in PIXEL_STREAM mode, in sample order -> float64 [spp, 3]."""
+    if n_chunks is None:
+        n_chunks = default_n_chunks(spp)
+    S, keep = make_scene(flat_scene, T)
+    Cm = make_camera(cam, T)
+    P = Params(int(width), int(height), int(spp), int(max_depth), int(seed), PIXEL_STREAM, 1,
+               int(n_chunks), int(product_order), 1, 0)
+    out = np.zeros((int(spp), 3), np.float64)
+    fn = getattr(lib(), "rtwo_pixel_samples_f64" if _is64(T) else "rtwo_pixel_samples_f32")
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    rc = fn(C.byref(S), C.byref(Cm), C.byref(P), int(i), int(j), _p(out))
+    del keep
+    if rc:
+        raise ValueError(f"rtwo_pixel_samples failed: {rc}")
+    return out
+
+
 def default_camera(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist, T=np.float32):
     L = lib()
     ct = _ct(T)
@@ -275,6 +294,12 @@ def ray_color(flat_scene, o, d, depth, state, product_order=PRODUCT_FORWARD, T=n
     fn(C.byref(S), _p(_v(o, T)), _p(_v(d, T)), int(depth), int(product_order), _p(st), _p(out))
     del keep
     return out, st
+
+
+def splitmix64(state):
+    """one SplitMix64 step on a 1-element uint64 array (advanced in place) -> output"""
+    fn = lib().rtwo_splitmix64; fn.argtypes = [C.c_void_p]; fn.restype = C.c_uint64
+    return int(fn(_p(state)))
 
 
 def rng_seed(seed):

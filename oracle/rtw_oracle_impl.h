@@ -358,6 +358,31 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
     return 0;
 }
 
+/* The radiance of every sample of pixel (i, j) (1-based, src/render.jl:23-24) in PIXEL_STREAM mode, in sample order:
+ * out[3 s .. 3 s + 2].  For the tests that bound the exact pixel sum against the reference's running
+ * `accum_color += ray_color(...)` (src/render.jl:38) on the SAME samples. */
+int FN(rtwo_pixel_samples_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P, int i, int j, double *out) {
+    if (!w || !cam || !P || !out) return -1;
+    const int W = P->width, H = P->height;
+    if (i < 1 || i > H || j < 1 || j > W || P->spp <= 0) return -2;
+    int nch = P->n_chunks > 0 ? P->n_chunks : 1;
+    int cs = (P->spp + nch - 1) / nch;
+    int nch_eff = (P->spp + cs - 1) / cs;
+    long pix = (long)(j - 1) * H + (i - 1);
+    T u = (T)((double)j / (double)W);
+    T v = (T)((double)(H - i) / (double)H);
+    octx c; c.draws = 0; c.segments = 0;
+    for (int ch = 0; ch < nch_eff; ++ch) {
+        rng_stream(P->seed, (uint64_t)pix, (uint64_t)ch, &c.rng);
+        int s1 = (ch + 1) * cs < P->spp ? (ch + 1) * cs : P->spp;
+        for (int s = ch * cs; s < s1; ++s) {
+            c3 col = FN(sample_)(&c, w, cam, P, u, v, s);
+            out[3 * s] = col.r; out[3 * s + 1] = col.g; out[3 * s + 2] = col.b;
+        }
+    }
+    return 0;
+}
+
 /* ---- host-side producers ----------------------------------------------------------------- */
 /* src/camera.jl:18-36 */
 void FN(rtwo_default_camera_)(const T lookfrom[3], const T lookat[3], const T vup[3], T vfov,

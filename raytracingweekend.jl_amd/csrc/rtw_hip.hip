@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
+#include <type_traits>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -78,38 +80,60 @@ struct RenderRec {
     }
 };
 
+// ---- persistent context of the host-buffer entry points (rtw_render_f32/_f64) -----------------------
+// What a caller that renders frame after frame through the Julia `render()` shim pays per call, besides the kernel, is the
+// image D2H: the uploaded scene (kd split + matrix-pipe operands: a dozen hipMalloc + synchronous copies), the stream and the
+// device image are kept per device and reused while the scene's bytes are the same.
+struct HostCtx {
+    int device = -1;
+    bool busy = false;                       // in use by a render call (guarded by DeviceCtx::mu)
+    hipStream_t stream = nullptr;
+    rtw_scene_handle scene = nullptr;        // the cached upload ...
+    std::vector<unsigned char> scene_key;    // ... and the exact bytes it was made from (precision tag, n, the nine arrays)
+    void *d_img = nullptr;  size_t d_cap = 0;      // device image / compact shard
+    void *d_aux = nullptr;  size_t aux_cap = 0;    // multi-device root: the gathered compact shards
+    hipEvent_t done_ev = nullptr;                  // multi-device: this shard has arrived in the root's gather buffer
+    ~HostCtx();
+};
+
 struct DeviceCtx {
     int device = -1;
     int num_cus = 0;
     std::mutex mu;
     std::vector<std::unique_ptr<RenderRec>> recs;
+    std::vector<std::unique_ptr<HostCtx>> host;    // at most RTW_HOST_CTX_POOL cached entries
 };
+#define RTW_HOST_CTX_POOL 8
+using CtxPtr = std::shared_ptr<DeviceCtx>;       // holders keep a context alive across a concurrent rtw_shutdown()
 
 std::mutex g_mu;
-std::vector<std::unique_ptr<DeviceCtx>> g_ctx;
+std::vector<CtxPtr> g_ctx;
 std::atomic<unsigned> g_generation{1};      // bumped by rtw_shutdown: invalidates every thread's "last render"
 
+void release_last();
 // what rtw_stats() reports: the records of the last render issued from this thread
 struct LastRender {
     unsigned generation = 0;
     bool resolved = false;
     std::vector<RenderRec *> recs;          // pending (device-resident call) or already summed into `agg`
+    std::vector<CtxPtr> ctxs;               // the contexts that own `recs` (kept alive; parallel to recs)
     rtw_stats_t agg;
+    ~LastRender();                          // a thread that exits hands its records back
 };
 thread_local LastRender g_last;
 
-int get_ctx(int device, DeviceCtx **out) {
+int get_ctx(int device, CtxPtr *out) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto &c : g_ctx)
-        if (c->device == device) { *out = c.get(); return 0; }
-    std::unique_ptr<DeviceCtx> c(new DeviceCtx());
+        if (c->device == device) { *out = c; return 0; }
+    CtxPtr c(new DeviceCtx());
     c->device = device;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(-20, "device %d is %s; librtw_hip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
     c->num_cus = prop.multiProcessorCount;
-    *out = c.get();
+    *out = c;
     g_ctx.push_back(std::move(c));
     return 0;
 }
@@ -138,21 +162,24 @@ int acquire_rec(DeviceCtx *ctx, RenderRec **out) {
     return 0;
 }
 
+void release_rec(const CtxPtr &ctx, RenderRec *r, bool finished) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (finished) r->done = true;
+    r->owned = false;
+}
+
 void release_last() {
-    if (g_last.generation == g_generation.load()) {
-        for (RenderRec *r : g_last.recs) {
-            DeviceCtx *ctx = nullptr;
-            {
-                std::lock_guard<std::mutex> lk(g_mu);
-                for (auto &c : g_ctx) if (c->device == r->device) ctx = c.get();
-            }
-            if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); r->owned = false; }
-        }
-    }
+    if (g_last.generation == g_generation.load())
+        for (size_t k = 0; k < g_last.recs.size(); ++k) release_rec(g_last.ctxs[k], g_last.recs[k], false);
     g_last.recs.clear();
+    g_last.ctxs.clear();                   // (a stale generation: the records died with their contexts' pools; only the shared_ptrs are dropped)
     g_last.resolved = false;
     g_last.generation = g_generation.load();
     memset(&g_last.agg, 0, sizeof g_last.agg);
+}
+LastRender::~LastRender() {
+    if (generation == g_generation.load())
+        for (size_t k = 0; k < recs.size(); ++k) release_rec(ctxs[k], recs[k], false);
 }
 
 int resolve_device(int device, int *out) {
@@ -191,6 +218,10 @@ struct rtw_scene_dev {
 };
 
 namespace {
+
+template <typename SceneT> bool s_has_bad_scene(const SceneT *s) {
+    return s->n > 0 && (!s->cx || !s->cy || !s->cz || !s->r || !s->kind || !s->ar || !s->ag || !s->ab || !s->param);
+}
 
 struct SceneDeleter { void operator()(rtw_scene_dev *h) const { rtw_scene_free(h); } };
 using ScenePtr = std::unique_ptr<rtw_scene_dev, SceneDeleter>;
@@ -451,7 +482,7 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     DeviceGuard guard;
     int dev;
     if (int rc = resolve_device(device, &dev)) return rc;
-    DeviceCtx *ctx;
+    CtxPtr ctx;
     if (int rc = get_ctx(dev, &ctx)) return rc;
     HIP_TRY(hipSetDevice(dev));
     using V4 = typename rtw::Vec4<T>::type;
@@ -557,15 +588,16 @@ long long local_tiles(const rtw_params *p) {
 
 // Enqueue one render (this shard's tiles) on `stream`; `rec` receives the counters and the kernel's events.
 template <typename T, typename CamT>
-int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, void *d_out, hipStream_t stream, RenderRec **rec_out) {
+int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, void *d_out, hipStream_t stream, RenderRec **rec_out, CtxPtr *ctx_out) {
     if (!scene || !cam || !d_out) return fail(-1, "null argument");
     if (scene->is_f64 != (sizeof(T) == 8)) return fail(-4, "scene handle precision does not match the call");
     int nch, cs;
     if (int rc = validate_params(p, &nch, &cs)) return rc;
     if (p->device >= 0 && p->device != scene->device)
         return fail(-4, "params.device %d != scene device %d", p->device, scene->device);
-    DeviceCtx *ctx;
+    CtxPtr ctx;
     if (int rc = get_ctx(scene->device, &ctx)) return rc;
+    *ctx_out = ctx;
     HIP_TRY(hipSetDevice(scene->device));
 
     rtw::KParams K;
@@ -647,7 +679,7 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     if (grid < 1) grid = 1;
 
     RenderRec *rec;
-    if (int rc = acquire_rec(ctx, &rec)) return rc;
+    if (int rc = acquire_rec(ctx.get(), &rec)) return rc;
     *rec_out = rec;
     rec->n_spheres = scene->n; rec->n_chunks = nch; rec->grid = (int)grid;
     HIP_TRY(hipMemsetAsync(rec->ctr, 0, sizeof(rtw::DevCounters), stream));
@@ -711,71 +743,117 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     DeviceGuard guard;
     if (p && p->n_devices > 1) return fail(-2, "the device-resident entry point renders on the scene's device only (n_devices = %d)", p->n_devices);
     RenderRec *rec = nullptr;
+    CtxPtr ctx;
     release_last();
-    int rc = launch_render<T>(scene, cam, p, d_out, (hipStream_t)stream_v, &rec);
-    if (rec) g_last.recs.push_back(rec);       // (also on a late error: released by the next call)
+    int rc = launch_render<T>(scene, cam, p, d_out, (hipStream_t)stream_v, &rec, &ctx);
+    if (rec) { g_last.recs.push_back(rec); g_last.ctxs.push_back(ctx); }       // (also on a late error: released by the next call)
     return rc;
 }
 
-// one shard of a host-buffer render: upload, render, copy back.  layout 0 -> `out` is the full frame;
-// compact (multi-device) -> the shard's tiles are scattered into the full frame on the host.
-template <typename T, typename SceneT, typename CamT>
-int render_host_shard(const SceneT *scene, const CamT *cam, rtw_params p, T *out, bool compact, rtw_stats_t *stats_out, char *err, size_t err_len) {
-    int rc = 0;
-    RenderRec *rec = nullptr;
-    rtw_scene_handle h_raw = nullptr;
-    void *d_out = nullptr;
-    T *staging = nullptr;
-    hipStream_t stream = nullptr;
-    do {
-        if ((rc = upload_scene<T>(scene, p.device, &h_raw))) break;
-        hipError_t e = hipSetDevice(h_raw->device);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { rc = fail((int)e, "stream: %s", hipGetErrorString(e)); break; }
-        p.device = h_raw->device;
-        const long long n_local = local_tiles(&p);
-        const size_t elems = compact ? (size_t)n_local * 64 * 3 : (size_t)p.width * (size_t)p.height * 3;
-        if (compact) p.flags |= RTW_FLAG_COMPACT_TILES;
-        if (elems == 0) break;
-        if ((e = hipMalloc(&d_out, elems * sizeof(T))) != hipSuccess) { rc = fail((int)e, "hipMalloc(image) failed: %s", hipGetErrorString(e)); break; }
-        if ((rc = launch_render<T>(h_raw, cam, &p, d_out, stream, &rec))) break;
-        if (!compact) {
-            e = hipMemcpyAsync(out, d_out, elems * sizeof(T), hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) { rc = fail((int)e, "image D2H failed: %s", hipGetErrorString(e)); break; }
-        } else {
-            if ((e = hipHostMalloc((void **)&staging, elems * sizeof(T), hipHostMallocDefault)) != hipSuccess) { rc = fail((int)e, "hipHostMalloc failed: %s", hipGetErrorString(e)); break; }
-            e = hipMemcpyAsync(staging, d_out, elems * sizeof(T), hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) { rc = fail((int)e, "shard D2H failed: %s", hipGetErrorString(e)); break; }
-            // tile-major compact shard -> column-major frame: tile k of this shard is global tile k*count + index
-            const int tiles_i = (p.height + 7) / 8;
-            for (long long k = 0; k < n_local; ++k) {
-                const long long t = k * p.shard_count + p.shard_index;
-                const int tj = (int)(t / tiles_i), ti = (int)(t % tiles_i);
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int j0 = tj * 8 + jj;
-                    if (j0 >= p.width) break;
-                    const int rows = std::min(8, p.height - ti * 8);
-                    // 8 consecutive rows of one column are contiguous in both layouts
-                    memcpy(out + ((size_t)j0 * p.height + (size_t)ti * 8) * 3, staging + ((size_t)k * 64 + (size_t)jj * 8) * 3, (size_t)rows * 3 * sizeof(T));
-                }
-            }
-        }
-        // the kernel has finished (stream synchronised above): read its counters while the stream still exists
-        memset(stats_out, 0, sizeof *stats_out);
-        rc = resolve_rec(rec, stats_out);
-    } while (0);
-    if (rec) {                                     // hand the record back: nothing refers to it any more
-        DeviceCtx *ctx = nullptr;
-        if (get_ctx(rec->device, &ctx) == 0) { std::lock_guard<std::mutex> lk(ctx->mu); if (rc == 0) rec->done = true; rec->owned = false; }
-    }
-    if (rc && err) snprintf(err, err_len, "%s", g_err);
-    if (staging) HIP_IGNORE(hipHostFree(staging));
-    if (d_out) HIP_IGNORE(hipFree(d_out));
+// ---- host-buffer path --------------------------------------------------------------------------------------------
+HostCtx::~HostCtx() {
+    if (device >= 0) HIP_IGNORE(hipSetDevice(device));
+    if (scene) rtw_scene_free(scene);
+    if (d_img) HIP_IGNORE(hipFree(d_img));
+    if (d_aux) HIP_IGNORE(hipFree(d_aux));
+    if (done_ev) HIP_IGNORE(hipEventDestroy(done_ev));
     if (stream) HIP_IGNORE(hipStreamDestroy(stream));
-    if (h_raw) rtw_scene_free(h_raw);
-    return rc;
+}
+
+template <typename SceneT>
+void scene_key_of(const SceneT *s, bool f64, std::vector<unsigned char> &key) {
+    using T = typename std::remove_cv<typename std::remove_pointer<decltype(s->cx)>::type>::type;
+    const size_t n = (size_t)(s->n > 0 ? s->n : 0);
+    key.clear();
+    key.reserve(16 + n * (8 * sizeof(T) + sizeof(int32_t)));
+    auto put = [&](const void *p, size_t b) { const unsigned char *q = (const unsigned char *)p; key.insert(key.end(), q, q + b); };
+    const int32_t head[2] = {f64 ? 1 : 0, s->n};
+    put(head, sizeof head);
+    if (n == 0) return;
+    const T *arrs[8] = {s->cx, s->cy, s->cz, s->r, s->ar, s->ag, s->ab, s->param};
+    for (const T *a : arrs) put(a, n * sizeof(T));
+    put(s->kind, n * sizeof(int32_t));
+}
+
+// the caller holds a HostCtx exclusively between acquire and release
+struct HostLease {
+    CtxPtr ctx;
+    HostCtx *hc = nullptr;
+    bool pooled = false;
+    ~HostLease() {
+        if (!hc) return;
+        if (pooled) { std::lock_guard<std::mutex> lk(ctx->mu); hc->busy = false; }
+        else delete hc;                               // more concurrent host renders than pool entries: a temporary
+    }
+};
+
+int acquire_host(int device, const std::vector<unsigned char> &key, HostLease *out) {
+    int dev;
+    if (int rc = resolve_device(device, &dev)) return rc;
+    CtxPtr ctx;
+    if (int rc = get_ctx(dev, &ctx)) return rc;
+    out->ctx = ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HostCtx *pick = nullptr;
+        for (auto &h : ctx->host) if (!h->busy && h->scene_key == key) { pick = h.get(); break; }     // same scene: nothing to upload
+        if (!pick) for (auto &h : ctx->host) if (!h->busy) { pick = h.get(); break; }
+        if (!pick && ctx->host.size() < RTW_HOST_CTX_POOL) {
+            ctx->host.emplace_back(new HostCtx());
+            pick = ctx->host.back().get();
+            pick->device = dev;
+        }
+        if (pick) { pick->busy = true; out->hc = pick; out->pooled = true; }
+    }
+    if (!out->hc) { out->hc = new HostCtx(); out->hc->device = dev; out->pooled = false; }
+    HostCtx *hc = out->hc;
+    HIP_TRY(hipSetDevice(dev));
+    if (!hc->stream) HIP_TRY(hipStreamCreateWithFlags(&hc->stream, hipStreamNonBlocking));
+    if (!hc->done_ev) HIP_TRY(hipEventCreateWithFlags(&hc->done_ev, hipEventDisableTiming));
+    return 0;
+}
+
+template <typename T, typename SceneT>
+int ensure_scene(HostCtx *hc, const SceneT *scene, const std::vector<unsigned char> &key) {
+    if (hc->scene && hc->scene_key == key) return 0;
+    if (hc->scene) { rtw_scene_free(hc->scene); hc->scene = nullptr; hc->scene_key.clear(); }
+    if (int rc = upload_scene<T>(scene, hc->device, &hc->scene)) return rc;
+    hc->scene_key = key;
+    return 0;
+}
+
+int ensure_dev(void **p, size_t *cap, size_t bytes) {
+    if (*cap >= bytes && *p) return 0;
+    if (*p) { HIP_IGNORE(hipFree(*p)); *p = nullptr; *cap = 0; }
+    HIP_TRY(hipMalloc(p, bytes));
+    *cap = bytes;
+    return 0;
+}
+
+// Device image -> the caller's (pageable) buffer: ONE hipMemcpyAsync on the context's stream.  Measured on the MI355X box
+// (tools/ubench_d2h.hip, 24.9 MB): straight into pageable memory 0.45 ms -- as fast as into pinned memory -- against 1.28 ms
+// through a pinned staging buffer + memcpy and 0.6 - 1.0 ms for chunked staging overlapped with 1 - 4 memcpy threads.
+int copy_out(HostCtx *hc, const void *d_src, void *out, size_t bytes) {
+    if (bytes == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(out, d_src, bytes, hipMemcpyDeviceToHost, hc->stream));
+    HIP_TRY(hipStreamSynchronize(hc->stream));
+    return 0;
+}
+
+// compact tile-major shards (shard r at r * pad_tiles tiles) -> the column-major frame (multi-device root)
+template <typename T>
+__global__ void untile_kernel(const T *__restrict__ gather, T *__restrict__ frame, int W, int H, int tiles_i, long n_tiles, int n_shards, long pad_tiles) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;         // (tile, slot)
+    const long t = g >> 6;
+    if (t >= n_tiles) return;
+    const int slot = (int)(g & 63);
+    const long r = t % n_shards, k = t / n_shards;
+    const int tj = (int)(t / tiles_i), ti = (int)(t % tiles_i);
+    const int i0 = ti * 8 + (slot & 7), j0 = tj * 8 + (slot >> 3);
+    if (i0 >= H || j0 >= W) return;
+    const T *src = gather + ((r * pad_tiles + k) * 64 + slot) * 3;
+    T *dst = frame + ((size_t)j0 * H + i0) * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 }
 
 template <typename T, typename SceneT, typename CamT>
@@ -800,38 +878,102 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
     } else if (p->n_devices < -1) {
         return fail(-2, "bad n_devices %d", p->n_devices);
     }
+    if (s_has_bad_scene(scene)) return fail(-1, "null scene array");
+    std::vector<unsigned char> key;
+    scene_key_of(scene, sizeof(T) == 8, key);
+
     if (devs.size() <= 1) {
+        // ---- one device: render into the cached device image, chunked D2H ----
+        HostLease L;
+        if (int rc = acquire_host(devs.size() == 1 ? devs[0] : p->device, key, &L)) return rc;
+        HostCtx *hc = L.hc;
+        if (int rc = ensure_scene<T>(hc, scene, key)) return rc;
         rtw_params q = *p;
-        if (devs.size() == 1) q.device = devs[0];
-        int rc = render_host_shard<T>(scene, cam, q, out, false, &g_last.agg, nullptr, 0);
+        q.device = hc->device; q.n_devices = 0; q.device_ids = nullptr;
+        const bool compact = (q.flags & RTW_FLAG_COMPACT_TILES) != 0;
+        const size_t elems = compact ? (size_t)local_tiles(&q) * 64 * 3 : (size_t)q.width * (size_t)q.height * 3;
+        if (elems == 0) { g_last.resolved = true; return 0; }
+        if (int rc = ensure_dev(&hc->d_img, &hc->d_cap, elems * sizeof(T))) return rc;
+        RenderRec *rec = nullptr;
+        CtxPtr rctx;
+        int rc = launch_render<T>(hc->scene, cam, &q, hc->d_img, hc->stream, &rec, &rctx);
+        if (!rc) rc = copy_out(hc, hc->d_img, out, elems * sizeof(T));
+        if (rc) (void)hipStreamSynchronize(hc->stream);           // nothing of this call may still be in flight when the lease ends
+        if (!rc) rc = resolve_rec(rec, &g_last.agg);
+        if (rec) release_rec(rctx, rec, rc == 0);
         g_last.resolved = rc == 0;
         return rc;
     }
+
+    // ---- several devices: shard r renders tiles t = r (mod N) compact on its own device and stream; the shards are gathered in
+    //      HBM of the first device (peer copies over xGMI; a shard on the root device renders straight into the gather buffer),
+    //      un-tiled there by one small kernel and the frame crosses PCIe once ----
     if (p->shard_count != 1) return fail(-2, "n_devices > 1 cannot be combined with shard_index/shard_count");
-    // one host thread per device renders tiles t = r (mod N) and scatters them into `out`; tiles are disjoint
+    if (p->flags & RTW_FLAG_COMPACT_TILES) return fail(-2, "n_devices > 1 writes the full frame (RTW_FLAG_COMPACT_TILES is a per-shard layout)");
     const int N = (int)devs.size();
-    std::vector<int> rcs(N, 0);
-    std::vector<rtw_stats_t> sts(N);
-    std::vector<std::vector<char>> errs(N, std::vector<char>(512, 0));
-    std::vector<std::thread> th;
+    std::vector<HostLease> L(N);
     for (int r = 0; r < N; ++r) {
-        th.emplace_back([&, r]() {
-            rtw_params q = *p;
-            q.device = devs[r]; q.shard_index = r; q.shard_count = N; q.n_devices = 0; q.device_ids = nullptr;
-            memset(&sts[r], 0, sizeof sts[r]);
-            rcs[r] = render_host_shard<T>(scene, cam, q, out, true, &sts[r], errs[r].data(), errs[r].size());
-        });
+        if (int rc = acquire_host(devs[r], key, &L[r])) return fail(rc, "device %d (shard %d of %d): %s", devs[r], r, N, std::string(g_err).c_str());
+        if (int rc = ensure_scene<T>(L[r].hc, scene, key)) return fail(rc, "device %d (shard %d of %d): %s", devs[r], r, N, std::string(g_err).c_str());
     }
-    for (auto &t : th) t.join();
-    for (int r = 0; r < N; ++r) if (rcs[r]) return fail(rcs[r], "device %d (shard %d of %d): %s", devs[r], r, N, errs[r].data());
+    HostCtx *root = L[0].hc;
+    rtw_params q0 = *p;
+    q0.shard_index = 0; q0.shard_count = N;
+    const long pad_tiles = local_tiles(&q0);                               // shard 0 owns the most tiles
+    const size_t shard_bytes = (size_t)pad_tiles * 192 * sizeof(T), frame_bytes = (size_t)p->width * p->height * 3 * sizeof(T);
+    HIP_TRY(hipSetDevice(root->device));
+    if (int rc = ensure_dev(&root->d_aux, &root->aux_cap, shard_bytes * N)) return rc;
+    if (int rc = ensure_dev(&root->d_img, &root->d_cap, frame_bytes)) return rc;
+    std::vector<RenderRec *> recs(N, nullptr);
+    std::vector<CtxPtr> rctx(N);
+    int rc = 0;
+    for (int r = 0; r < N && !rc; ++r) {
+        HostCtx *hc = L[r].hc;
+        rtw_params q = *p;
+        q.device = hc->device; q.shard_index = r; q.shard_count = N; q.n_devices = 0; q.device_ids = nullptr;
+        q.flags |= RTW_FLAG_COMPACT_TILES;
+        const size_t my_bytes = (size_t)local_tiles(&q) * 192 * sizeof(T);
+        char *slot = (char *)root->d_aux + (size_t)r * shard_bytes;
+        if (my_bytes == 0) continue;
+        void *d_out = slot;
+        if (hc->device != root->device) {
+            if ((rc = ensure_dev(&hc->d_img, &hc->d_cap, my_bytes))) break;
+            d_out = hc->d_img;
+        }
+        if ((rc = launch_render<T>(hc->scene, cam, &q, d_out, hc->stream, &recs[r], &rctx[r]))) break;
+        hipError_t e = hipSuccess;
+        if (hc->device != root->device) e = hipMemcpyPeerAsync(slot, root->device, d_out, hc->device, my_bytes, hc->stream);
+        if (e == hipSuccess) e = hipEventRecord(hc->done_ev, hc->stream);
+        if (e == hipSuccess && hc != root) { e = hipSetDevice(root->device); if (e == hipSuccess) e = hipStreamWaitEvent(root->stream, hc->done_ev, 0); }
+        if (e != hipSuccess) rc = fail((int)e, "device %d (shard %d of %d): gather failed: %s", hc->device, r, N, hipGetErrorString(e));
+    }
+    if (!rc) {
+        hipError_t e = hipSetDevice(root->device);
+        const long n_tiles = (long)((p->height + 7) / 8) * ((p->width + 7) / 8);
+        if (e == hipSuccess && n_tiles > 0) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(untile_kernel<T>, dim3((unsigned)((n_tiles * 64 + 255) / 256)), dim3(256), 0, root->stream,
+                               (const T *)root->d_aux, (T *)root->d_img, p->width, p->height, (p->height + 7) / 8, n_tiles, N, pad_tiles);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) rc = fail((int)e, "un-tile kernel: %s", hipGetErrorString(e));
+        if (!rc) rc = copy_out(root, root->d_img, out, frame_bytes);
+    }
+    // every stream of this call drains before the leases end, also on an error
+    for (int r = 0; r < N; ++r) { HIP_IGNORE(hipSetDevice(L[r].hc->device)); HIP_IGNORE(hipStreamSynchronize(L[r].hc->stream)); }
     rtw_stats_t &a = g_last.agg;                       // sums over the devices; times: the maximum
     for (int r = 0; r < N; ++r) {
-        a.samples += sts[r].samples; a.segments += sts[r].segments; a.sphere_tests += sts[r].sphere_tests;
-        a.kernel_ms = std::max(a.kernel_ms, sts[r].kernel_ms); a.total_ms = std::max(a.total_ms, sts[r].total_ms);
-        a.n_chunks = sts[r].n_chunks; a.grid_blocks = std::max(a.grid_blocks, sts[r].grid_blocks); a.block_threads = 256;
+        if (!recs[r]) continue;
+        rtw_stats_t st;
+        memset(&st, 0, sizeof st);
+        if (!rc) rc = resolve_rec(recs[r], &st);
+        release_rec(rctx[r], recs[r], rc == 0);
+        a.samples += st.samples; a.segments += st.segments; a.sphere_tests += st.sphere_tests;
+        a.kernel_ms = std::max(a.kernel_ms, st.kernel_ms); a.total_ms = std::max(a.total_ms, st.total_ms);
+        a.n_chunks = st.n_chunks; a.grid_blocks = std::max(a.grid_blocks, st.grid_blocks); a.block_threads = 256;
     }
-    g_last.resolved = true;
-    return 0;
+    g_last.resolved = rc == 0;
+    return rc;
 }
 
 // T0 unit entry point: host slots -> device -> unit_kernel -> host slots
@@ -846,7 +988,7 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
     DeviceGuard guard;
     int dev;
     if (int rc = resolve_device(-1, &dev)) return rc;
-    DeviceCtx *ctx;
+    CtxPtr ctx;
     if (int rc = get_ctx(dev, &ctx)) return rc;
     rtw_scene_handle h_raw = nullptr;
     rtw::DevScene<T> S;
@@ -971,6 +1113,8 @@ int rtw_shutdown(void) {
         HIP_IGNORE(hipSetDevice(c->device));
         std::lock_guard<std::mutex> lk2(c->mu);
         c->recs.clear();
+        // (host contexts in use by a render in flight on another thread stay alive with their DeviceCtx: that thread holds a CtxPtr)
+        c->host.erase(std::remove_if(c->host.begin(), c->host.end(), [](const std::unique_ptr<HostCtx> &h) { return !h->busy; }), c->host.end());
     }
     g_ctx.clear();
     return 0;

@@ -15,7 +15,8 @@ enum UnitOp {
     U_FX_SUM = 12,           // exact 64.64 accumulation of 8 doubles -> rounded sum, poison count
     U_HIT_WORLD_MFMA = 13,   // hit_world_mfma (pass 1 on the matrix pipe), scene staged in LDS; tmin / tmax of ray 0 serve the whole launch
     U_HIT_WORLD_MFMA_CULL = 14,   // hit_world_mfma with block culling (RTW_FLAG_GROUP_CULL on the matrix pipe), cull layout staged in LDS
-    U_NUM_OPS = 15
+    U_NEAR_ZERO = 15,        // near_zero(v) (src/vec.jl:20): squared length against the Float64 literal 1e-5
+    U_NUM_OPS = 16
 };
 
 __host__ __device__ inline int unit_in_slots(int op) {
@@ -28,6 +29,7 @@ __host__ __device__ inline int unit_in_slots(int op) {
         case U_GET_RAY: return 4;       // state[2], s, t
         case U_SKYCOLOR: return 3;      // d[3]
         case U_RNG: return 2;           // state[2]
+        case U_NEAR_ZERO: return 3;     // v[3]
         case U_HIT_WORLD: case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: case U_HIT_WORLD_MFMA: case U_HIT_WORLD_MFMA_CULL: return 8;     // o[3], d[3], tmin, tmax
         case U_RAY_COLOR: return 9;     // state[2], o[3], d[3], depth
         case U_FX_SUM: return 8;        // 8 binary64 values
@@ -44,6 +46,7 @@ __host__ __device__ inline int unit_out_slots(int op) {
         case U_GET_RAY: return 8;       // state[2], o[3], d[3]
         case U_SKYCOLOR: return 3;
         case U_RNG: return 6;           // state[2], 4 uniforms
+        case U_NEAR_ZERO: return 2;     // near_zero(v), squared_length(v) (src/vec.jl:19-20)
         case U_HIT_WORLD: case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: case U_HIT_WORLD_MFMA: case U_HIT_WORLD_MFMA_CULL: return 9;     // idx, t, p[3], n[3], front
         case U_RAY_COLOR: return 6;     // state[2], colour[3], segments
         case U_FX_SUM: return 2;        // sum, poisoned
@@ -111,6 +114,11 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
             Rng rng = {as_u64(x[0]), as_u64(x[1])};
             for (int k = 0; k < 4; ++k) { T u; trand(rng, u); y[2 + k] = (double)u; }
             y[0] = as_f64(rng.x); y[1] = as_f64(rng.y);
+        } break;
+        case U_NEAR_ZERO: {
+            const V3<T> v = ld3<T>(x);
+            y[0] = near_zero(v) ? 1.0 : 0.0;
+            y[1] = (double)dot(v, v);
         } break;
         case U_HIT_WORLD: {
             V3<T> o = {0, 0, 0}, d = {0, 0, 1};

@@ -79,10 +79,16 @@ class DeviceRenderer:
 
     def render_into(self, d_out_ptr, image_width, n_samples, *, depth=16, seed=1, n_chunks=0,
                     shard_index=0, shard_count=1, stream=0, gamma=True, group_cull=False, compact=False,
-                    scan_valu=False):
+                    scan_valu=False, n_elems=None):
         """Enqueue one render into device memory at ``d_out_ptr``: H*W*3 elements, or with
-        ``compact=True`` only this shard's tiles (``shard.compact_elems``), tile-major."""
+        ``compact=True`` only this shard's tiles (``shard.compact_elems`` elements -- whole 8x8 tiles, which for a ragged
+        frame can exceed H*W*3), tile-major.  ``n_elems``: the buffer's length in elements; checked when given."""
         height = image_height(image_width)
+        if n_elems is not None:
+            from .shard import compact_elems
+            need = compact_elems(image_width, shard_index, shard_count) if compact else height * int(image_width) * 3
+            if int(n_elems) < need:
+                raise ValueError(f"output buffer holds {n_elems} elements, this render writes {need}")
         flags = ((_capi.FLAG_GROUP_CULL if group_cull else 0) | (_capi.FLAG_COMPACT_TILES if compact else 0) |
                  (_capi.FLAG_SCAN_VALU if scan_valu else 0))
         P = _capi.make_params(image_width, height, n_samples, depth, seed, n_chunks, shard_index, shard_count,

@@ -74,6 +74,8 @@ def render_sharded(render_shard, image_width, *, group=None, dst=0, mode="reduce
     tile-major shard (``compact_elems`` elements, or longer: only that prefix is used); rank ``dst``
     gets the assembled frame as a flat ``H*W*3`` tensor in ``Matrix{RGB{T}}`` layout.
 
+    ``dst`` is a GLOBAL rank (what ``torch.distributed.reduce/gather`` take); with a sub-``group`` it must be a member.
+
     Returns the full framebuffer on rank ``dst`` and the local (partial) one elsewhere.
     ``render_shard`` is the HIP path in production (DeviceRenderer.render_into on this rank's GPU);
     the CPU tests pass a stand-in to exercise the partition + collective under gloo.
@@ -85,7 +87,11 @@ def render_sharded(render_shard, image_width, *, group=None, dst=0, mode="reduce
         raise ValueError("mode must be 'reduce' or 'gather'")
     W, H = int(image_width), image_height(image_width)
     on = dist.is_available() and dist.is_initialized()
-    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)      # group-relative: the shard index
+    # the collectives take a GLOBAL destination rank; "am I the destination" is decided on global ranks too
+    is_dst = (dist.get_rank() == int(dst)) if on else True
+    if on and group is not None and dist.get_group_rank(group, int(dst)) < 0:
+        raise ValueError(f"dst={dst} is not a member of the group")
     fb = render_shard(rank, world)
     if mode == "reduce":
         if world > 1:
@@ -100,12 +106,12 @@ def render_sharded(render_shard, image_width, *, group=None, dst=0, mode="reduce
         piece[:mine.numel()] = mine
     pieces = None
     if world > 1:
-        if rank == dst:
+        if is_dst:
             pieces = [torch.empty_like(piece) for _ in range(world)]
         dist.gather(piece, pieces, dst=dst, group=group)
     else:
         pieces = [piece]
-    if rank != dst:
+    if not is_dst:
         return fb
     key = (W, world, str(fb.device))
     if key not in _index_cache:

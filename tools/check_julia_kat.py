@@ -27,6 +27,52 @@ HIT_RAYS = [((13, 2, 3), (-13, -2.2, -3.1)), ((0, 0, 0), (0.1, -0.05, -1)), ((0.
 HIT_SPHERES = [((0, -1000, -1), 1000), ((0, 0, -1), 0.5), ((0, 0, -1), -0.4), ((0, 1, 0), 1)]
 
 
+M64 = (1 << 64) - 1
+
+
+def _sm_mix(z):
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def seed_expansion_counter(seed):
+    """(x, y) = the first two outputs of a SplitMix64 generator seeded with `seed`: the state is a Weyl counter stepped by the
+    golden gamma, each output mixes the counter (Vigna's splitmix64.c; what oracle/rtw_oracle.c rng_seed_int restates)."""
+    s1 = (seed + 0x9E3779B97F4A7C15) & M64
+    s2 = (s1 + 0x9E3779B97F4A7C15) & M64
+    return _sm_mix(s1), _sm_mix(s2)
+
+
+def seed_expansion_output_fed(seed):
+    """(x, y) when a stateless one-step function `splitmix64(x) -> output` is chained: each OUTPUT is the next call's input
+    (x = f(seed), y = f(x)) -- the other plausible reading of RandomNumbers.jl's `init_seed(seed, UInt64, 2)`."""
+    f = lambda v: _sm_mix((v + 0x9E3779B97F4A7C15) & M64)
+    x = f(seed & M64)
+    return x, f(x)
+
+
+def after_one_step(x, y):
+    """the xoroshiro128+ (55, 14, 36) state after one discarded output"""
+    rotl = lambda v, k: ((v << k) | (v >> (64 - k))) & M64
+    s1 = x ^ y
+    return rotl(x, 55) ^ s1 ^ ((s1 << 14) & M64), rotl(s1, 36)
+
+
+def classify_seed_expansion(seed, state):
+    """Which known expansion produces `state` = (x, y) right after Xoroshiro128Plus(seed)?  None if none does."""
+    state = (int(state[0]), int(state[1]))
+    for name, fn in (("counter-stepped SplitMix64 (oracle/rtw_oracle.c as restated)", seed_expansion_counter),
+                     ("output-fed SplitMix64 (x = f(seed), y = f(x)): change rng_seed_int in oracle/rtw_oracle.c and "
+                      "raytracingweekend.jl_amd/rng.py accordingly", seed_expansion_output_fed)):
+        xy = fn(seed)
+        if state == after_one_step(*xy):
+            return name
+        if state == xy:
+            return name + ", WITHOUT the discarded first output"
+    return None
+
+
 def fmt(x, T):
     return ("%.9g" if T is np.float32 else "%.17g") % float(x)
 
@@ -120,6 +166,15 @@ def check(path):
         item(f"StaticArrays normalize/dot {name}", [f"normalize {name}", f"dot {name}"], "inv(norm(v)) * v; (x1y1 + x2y2) + x3y3", T)
         item(f"tand {name}", [f"tand {name}"], "src/camera.jl:23", T)
         item(f"hit(::Sphere) {name} (@fastmath contraction of the discriminant)", [f"hit {name}"], "src/hit.jl:12-35", T)
+    # a failing seed expansion: say WHICH expansion Julia uses (two are plausible; the package source is not in the reference tree)
+    for seed in (1, 2):
+        k = f"rng_state seed={seed}"
+        if k in got and got[k] != want.get(k):
+            try:
+                st = tuple(int(v, 16) for v in got[k].split())
+                print(f"seed expansion, seed {seed}: Julia's state matches -> {classify_seed_expansion(seed, st) or 'NEITHER known expansion: inspect RandomNumbers.jl src/common.jl init_seed'}")
+            except ValueError:
+                pass
     print(f"{'item':72s} result")
     for name, ok, why, missing, bad in items:
         print(f"{name:72s} {'PASS' if ok else 'FAIL'}   [{why}]" + ("" if ok else f"  missing {missing[:3]} differing {bad[:3]}"))

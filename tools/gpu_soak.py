@@ -1,68 +1,89 @@
 #!/usr/bin/env python3
 """Soak test of the matrix-pipe filter: random scans (unit ops 13 and 14 vs the oracle) with fresh seeds for a
 given number of seconds, then random small renders in every scan mode vs the oracle.
-usage: python tools/gpu_soak.py [seconds=300] [first_seed=1000]   (needs the GPU; prints one summary line per round)"""
+usage: python tools/gpu_soak.py [seconds=300] [first_seed=1000]   (needs the GPU; prints one summary line per part)
+A 60-second slice of the same two loops gates the GPU suite: tests/test_gpu_round3.py::test_soak_slice."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
-    sys.path.insert(0, p)
+    if p not in sys.path:
+        sys.path.insert(0, p)
 import numpy as np
-import rtw_oracle as O
-import rtw_amd as R
-from test_gpu_units import run_unit
-from test_gpu_round2 import _stress_scene, _stress_rays
-from test_gpu_render import gpu_render
-from conftest import load_golden
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-O.build(); O.lib()
-t0 = time.time()
-rays_total = bad_total = rounds = 0
-while time.time() - t0 < budget * 0.7:
-    rng = np.random.default_rng(seed)
-    T = np.float32 if seed % 2 == 0 else np.float64
-    n = int(rng.choice([1, 2, 7, 33, 64, 65, 200, 485, 600, 1500]))
-    scale = float(rng.choice([1e-3, 0.1, 1, 10, 12, 100, 1e3, 1e4, 1e6]))
-    m = 131072
-    flat = _stress_scene(rng, n, T, scale)
-    rays = _stress_rays(rng, flat, m, T, scale)
-    tmin = T(1e-4)
-    ref_idx, ref_t = O.hit_world_batch(flat, rays, tmin, np.inf, T)
-    x = np.concatenate([rays.astype(np.float64), np.full((m, 1), float(tmin)), np.full((m, 1), np.inf)], 1)
-    for op in (13, 14):                      # the matrix-pipe scan and its block-culling form
-        y = run_unit(op, x, 9, T, flat=flat)
-        bad = (y[:, 0].astype(np.int64) != ref_idx) | ((ref_idx >= 0) & (y[:, 1] != ref_t.astype(np.float64)))
-        rays_total += m; bad_total += int(bad.sum())
-        if bad.any():
-            print(f"MISMATCH op {op} seed {seed} n {n} scale {scale} T {T.__name__}: {int(bad.sum())} rays, first {np.flatnonzero(bad)[:5]}", flush=True)
-    rounds += 1
-    seed += 1
-print(f"scan soak: {rounds} rounds, {rays_total} rays, {bad_total} mismatches, {time.time() - t0:.0f} s", flush=True)
 
-g0 = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
-imgs = bad_imgs = 0
-while time.time() - t0 < budget:
-    rng = np.random.default_rng(seed)
-    T = np.float32 if seed % 2 == 0 else np.float64
-    n = int(rng.choice([3, 20, 100, 485]))
-    scale = float(rng.choice([0.5, 1, 4, 30]))
-    flat = dict(n=n, cx=(rng.uniform(-4, 4, n) * scale).astype(T), cy=(rng.uniform(-2, 2, n) * scale).astype(T),
-                cz=(rng.uniform(-9, -2, n) * scale).astype(T), r=(rng.uniform(0.05, 0.6, n) * scale * rng.choice([1, 1, 1, -1], n)).astype(T),
-                kind=rng.integers(0, 3, n).astype(np.int32), ar=rng.uniform(0, 1, n).astype(T), ag=rng.uniform(0, 1, n).astype(T),
-                ab=rng.uniform(0, 1, n).astype(T), param=np.where(rng.random(n) < 0.5, 1.5, rng.uniform(0, 1, n)).astype(T))
-    flat["cx"][0], flat["cy"][0], flat["cz"][0], flat["r"][0] = 0, T(-100.5 * scale), T(-1 * scale), T(100 * scale)   # a ground sphere
-    cam = R.default_camera((rng.uniform(-3, 3) * scale, rng.uniform(0.2, 3) * scale, rng.uniform(0.5, 6) * scale), (0, 0, -5 * scale), (0, 1, 0),
-                           float(rng.uniform(20, 90)), 16 / 9, float(rng.choice([0.0, 0.1 * scale])), 5.0 * scale, elem_type=T)
-    camd = {k: np.asarray(getattr(cam, k)) for k in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w", "lens_radius")}
-    g = dict(g0, flat=flat, cam=camd, image=np.zeros((1, 1, 3), T))
-    ref, ost = O.render(flat, cam, 64, 36, 6, T=T, max_depth=12, seed=seed, n_chunks=3)
-    for flags in (0, 4, 1, 5):
-        img, st = gpu_render(g, width=64, height=36, spp=6, n_chunks=3, max_depth=12, seed=seed, flags=flags)
-        imgs += 1
-        if not (np.array_equal(img, ref, equal_nan=True) and st.segments == ost["segments"]):
-            bad_imgs += 1
-            print(f"IMAGE MISMATCH seed {seed} n {n} scale {scale} flags {flags}: {(img != ref).sum()} channels", flush=True)
-    seed += 1
-print(f"render soak: {imgs} images (4 scan modes), {bad_imgs} mismatches; total {time.time() - t0:.0f} s", flush=True)
-sys.exit(1 if (bad_total or bad_imgs) else 0)
+def scan_rounds(seconds, seed, log=print):
+    """Random scenes (1 ... 1500 spheres, extents 1e-3 ... 1e6, both precisions) x 131 072 random rays through the matrix-pipe
+    scan and its block-culling form vs the oracle.  -> (rounds, rays, mismatches, next seed)"""
+    import rtw_oracle as O
+    from test_gpu_units import run_unit
+    from test_gpu_round2 import _stress_scene, _stress_rays
+    t0 = time.time()
+    rays_total = bad_total = rounds = 0
+    while time.time() - t0 < seconds:
+        rng = np.random.default_rng(seed)
+        T = np.float32 if seed % 2 == 0 else np.float64
+        n = int(rng.choice([1, 2, 7, 33, 64, 65, 200, 485, 600, 1500]))
+        scale = float(rng.choice([1e-3, 0.1, 1, 10, 12, 100, 1e3, 1e4, 1e6]))
+        m = 131072
+        flat = _stress_scene(rng, n, T, scale)
+        rays = _stress_rays(rng, flat, m, T, scale)
+        tmin = T(1e-4)
+        ref_idx, ref_t = O.hit_world_batch(flat, rays, tmin, np.inf, T)
+        x = np.concatenate([rays.astype(np.float64), np.full((m, 1), float(tmin)), np.full((m, 1), np.inf)], 1)
+        for op in (13, 14):                      # the matrix-pipe scan and its block-culling form
+            y = run_unit(op, x, 9, T, flat=flat)
+            bad = (y[:, 0].astype(np.int64) != ref_idx) | ((ref_idx >= 0) & (y[:, 1] != ref_t.astype(np.float64)))
+            rays_total += m; bad_total += int(bad.sum())
+            if bad.any():
+                log(f"MISMATCH op {op} seed {seed} n {n} scale {scale} T {T.__name__}: {int(bad.sum())} rays, first {np.flatnonzero(bad)[:5]}")
+        rounds += 1
+        seed += 1
+    return rounds, rays_total, bad_total, seed
+
+
+def render_rounds(seconds, seed, log=print):
+    """Random small scenes / cameras rendered in all four scan modes vs the oracle.  -> (images, mismatches, next seed)"""
+    import rtw_oracle as O
+    import rtw_amd as R
+    from test_gpu_render import gpu_render
+    from conftest import load_golden
+    g0 = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
+    t0 = time.time()
+    imgs = bad_imgs = 0
+    while time.time() - t0 < seconds:
+        rng = np.random.default_rng(seed)
+        T = np.float32 if seed % 2 == 0 else np.float64
+        n = int(rng.choice([3, 20, 100, 485]))
+        scale = float(rng.choice([0.5, 1, 4, 30]))
+        flat = dict(n=n, cx=(rng.uniform(-4, 4, n) * scale).astype(T), cy=(rng.uniform(-2, 2, n) * scale).astype(T),
+                    cz=(rng.uniform(-9, -2, n) * scale).astype(T), r=(rng.uniform(0.05, 0.6, n) * scale * rng.choice([1, 1, 1, -1], n)).astype(T),
+                    kind=rng.integers(0, 3, n).astype(np.int32), ar=rng.uniform(0, 1, n).astype(T), ag=rng.uniform(0, 1, n).astype(T),
+                    ab=rng.uniform(0, 1, n).astype(T), param=np.where(rng.random(n) < 0.5, 1.5, rng.uniform(0, 1, n)).astype(T))
+        flat["cx"][0], flat["cy"][0], flat["cz"][0], flat["r"][0] = 0, T(-100.5 * scale), T(-1 * scale), T(100 * scale)   # a ground sphere
+        cam = R.default_camera((rng.uniform(-3, 3) * scale, rng.uniform(0.2, 3) * scale, rng.uniform(0.5, 6) * scale), (0, 0, -5 * scale), (0, 1, 0),
+                               float(rng.uniform(20, 90)), 16 / 9, float(rng.choice([0.0, 0.1 * scale])), 5.0 * scale, elem_type=T)
+        camd = {k: np.asarray(getattr(cam, k)) for k in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w", "lens_radius")}
+        g = dict(g0, flat=flat, cam=camd, image=np.zeros((1, 1, 3), T))
+        ref, ost = O.render(flat, cam, 64, 36, 6, T=T, max_depth=12, seed=seed, n_chunks=3)
+        for flags in (0, 4, 1, 5):
+            img, st = gpu_render(g, width=64, height=36, spp=6, n_chunks=3, max_depth=12, seed=seed, flags=flags)
+            imgs += 1
+            if not (np.array_equal(img, ref, equal_nan=True) and st.segments == ost["segments"]):
+                bad_imgs += 1
+                log(f"IMAGE MISMATCH seed {seed} n {n} scale {scale} flags {flags}: {(img != ref).sum()} channels")
+        seed += 1
+    return imgs, bad_imgs, seed
+
+
+if __name__ == "__main__":
+    import rtw_oracle as O
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    O.build(); O.lib()
+    t0 = time.time()
+    say = lambda s: print(s, flush=True)
+    rounds, rays_total, bad_total, seed = scan_rounds(budget * 0.7, seed, say)
+    say(f"scan soak: {rounds} rounds, {rays_total} rays, {bad_total} mismatches, {time.time() - t0:.0f} s")
+    imgs, bad_imgs, seed = render_rounds(budget - (time.time() - t0), seed, say)
+    say(f"render soak: {imgs} images (4 scan modes), {bad_imgs} mismatches; total {time.time() - t0:.0f} s")
+    sys.exit(1 if (bad_total or bad_imgs) else 0)
