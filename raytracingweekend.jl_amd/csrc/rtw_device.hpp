@@ -627,42 +627,70 @@ __device__ __forceinline__ double lane_get(double v, unsigned src_lane) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// Walk n pairs of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
+// Pass 1 flags GROUPS of RTW_SCAN_GROUP spheres (consecutive result registers of one lane = consecutive spheres): the sign
+// bits of a group's filter values are ANDed with fast-class bit operations (v_bitop3_b32 / v_and_b32: 2.4 cycles) and only
+// the group's bit goes through the slow-class v_alignbit_b32 (4.3 cycles) -- 16 + 8 instead of 32 instructions per block of
+// 32 spheres; pass 2 applies the exact test to every member of a flagged group.  1 (default): one sphere per list entry.
+// Measured (1080p x 1000 spp Float32, same box): groups of 4 378.3 ms, single spheres 372.6 ms -- the slow-class alignbits
+// already pair with other waves' FMA-class instructions, and pass 2 pays four exact tests per entry.  Kept for A/B runs.
+#ifndef RTW_SCAN_GROUP
+#define RTW_SCAN_GROUP 1
+#endif
+static_assert(RTW_SCAN_GROUP == 1 || RTW_SCAN_GROUP == 4, "groups of 1 or 4 result registers");
+#ifndef RTW_SCAN_SKIP
+#define RTW_SCAN_SKIP 0      // 1: wave-level early-out per half block (hit_world_mfma).  Measured: no gain (84.2 vs 84.8 ms at 200 spp) --
+                             // the compiler if-converts it, and the sign collection it would skip costs 13 % of the kernel in all
+#endif
+
+// Walk n entries of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
 struct NoOrig {};
 template <typename T, typename SRC, typename ORIG = NoOrig>
 __device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
     constexpr bool CULLED = !__is_same(ORIG, NoOrig);      // device order != the caller's order: ties go by orig[], the key carries both
+    constexpr unsigned G = RTW_SCAN_GROUP;
     using V4 = typename Vec4<T>::type;
     __builtin_amdgcn_wave_barrier();
     for (unsigned p0 = 0; p0 < n; p0 += 64u) {
         const unsigned p = p0 + lane;
         const bool valid = p < n;
         const unsigned e = ws.pairs[valid ? p : 0u];
-        // entry = recording lane (H, j) << 16 | block << 5 | b:  ray j + 32 (b >> 4),  sphere 32 block + 16 H + (b & 15)
-        const unsigned owner = ((e >> 16) & 31u) + ((e & 16u) << 1), sph = (e & 0xffefu) + ((e >> 17) & 16u);
+        // entry = recording lane (H, j) << 16 | block << 5 | b.   G = 1: b = half << 4 | result register: ray j + 32 (b >> 4), sphere
+        // 32 block + 16 H + (b & 15).   G = 4: b = half << 2 | group: ray j + 32 (b >> 2), spheres 32 block + 16 H + 4 (b & 3) + 0..3
+        unsigned owner, sph0;
+        if constexpr (G == 1) { owner = ((e >> 16) & 31u) + ((e & 16u) << 1); sph0 = (e & 0xffefu) + ((e >> 17) & 16u); }
+        else { owner = ((e >> 16) & 31u) + ((e & 4u) << 3); sph0 = (e & 0xffe0u) + ((e >> 17) & 16u) + ((e & 3u) << 2); }
         const V3<T> po = {lane_get(o.x, owner), lane_get(o.y, owner), lane_get(o.z, owner)};
         const V3<T> pd = {lane_get(d.x, owner), lane_get(d.y, owner), lane_get(d.z, owner)};
-        const V4 s = src[sph];
-        T hb, disc, root = 0;
-        sphere_disc<T>(s.x, s.y, s.z, s.w, po, pd, hb, disc);
-        const bool hit = valid && sphere_root<T>(hb, disc, tmin, (T)__builtin_huge_val(), root);
-        unsigned tie = sph;                                  // larger = later in the caller's list
-        if constexpr (CULLED) tie = ((unsigned)orig[sph] << 16) | sph;
-        if constexpr (sizeof(T) == 4) {
-            if (hit) {
-                const unsigned low = CULLED ? ((0xffffu - (tie >> 16)) << 16) | (tie & 0xffffu) : 0xffffffffu - tie;
-                const unsigned long long key = ((unsigned long long)__float_as_uint(root) << 32) | (unsigned long long)low;
-                __hip_atomic_fetch_min(&ws.keys[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        V4 sg[G];
+#pragma unroll
+        for (unsigned m = 0; m < G; ++m) sg[m] = src[sph0 + m];
+#pragma unroll
+        for (unsigned m = 0; m < G; ++m) {
+            const unsigned sph = sph0 + m;
+            const V4 s = sg[m];
+            T hb, disc, root = 0;
+            sphere_disc<T>(s.x, s.y, s.z, s.w, po, pd, hb, disc);
+            if (G > 1 && !__any(valid && !(disc < T(0)))) continue;           // no entry has a candidate at this position
+            const bool hit = valid && sphere_root<T>(hb, disc, tmin, (T)__builtin_huge_val(), root);
+            unsigned tie = sph;                                  // larger = later in the caller's list
+            if constexpr (CULLED) tie = ((unsigned)orig[sph] << 16) | sph;
+            if constexpr (sizeof(T) == 4) {
+                if (hit) {
+                    const unsigned low = CULLED ? ((0xffffu - (tie >> 16)) << 16) | (tie & 0xffffu) : 0xffffffffu - tie;
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(root) << 32) | (unsigned long long)low;
+                    __hip_atomic_fetch_min(&ws.keys[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                const unsigned long long tb = (unsigned long long)__double_as_longlong(root);
+                unsigned long long old = 0ull;
+                if (hit) old = __hip_atomic_fetch_min(&ws.keys[owner], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long cur = ws.keys[owner];
+                if (hit && tb == cur && old > tb) ws.kidx[owner] = 0u;              // the candidate that lowered the minimum to its final value of this step
+                __builtin_amdgcn_wave_barrier();
+                if (hit && tb == cur) __hip_atomic_fetch_max(&ws.kidx[owner], tie + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_wave_barrier();
             }
-        } else {
-            const unsigned long long tb = (unsigned long long)__double_as_longlong(root);
-            unsigned long long old = 0ull;
-            if (hit) old = __hip_atomic_fetch_min(&ws.keys[owner], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_wave_barrier();
-            const unsigned long long cur = ws.keys[owner];
-            if (hit && tb == cur && old > tb) ws.kidx[owner] = 0u;              // the candidate that lowered the minimum to its final value of this step
-            __builtin_amdgcn_wave_barrier();
-            if (hit && tb == cur) __hip_atomic_fetch_max(&ws.kidx[owner], tie + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -777,33 +805,74 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         unsigned mask = 0;
         const rtw_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         auto eval = [&](const rtw_f16v &Wv) {
+            if constexpr (RTW_SCAN_GROUP == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]), 31);
+                for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]), 31);
+            } else {
+                // sign of (a & b & c & d) is set iff all four filter values are negative: no member is a candidate
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    const unsigned g = __builtin_amdgcn_bitop3_b32(__float_as_uint(Wv[r]), __float_as_uint(Wv[r + 1]), __float_as_uint(Wv[r + 2]), 0x80) &
+                                       __float_as_uint(Wv[r + 3]);
+                    mask = __builtin_amdgcn_alignbit(mask, g, 31);
+                }
+            }
         };
+        // Half of the (wave, block) evaluations find no candidate in ANY lane (rays of a wave are neighbours): the sign bits of
+        // a half block's 16 filter values are ANDed first (8 FMA-class v_bitop3_b32 / v_and_b32) and the 16 slow-class
+        // v_alignbit_b32 run only when some lane has a non-negative value.  true = no lane has a candidate in Wv.
+        auto none = [&](const rtw_f16v &Wv) -> bool {
+            unsigned t = __builtin_amdgcn_bitop3_b32(__float_as_uint(Wv[0]), __float_as_uint(Wv[1]), __float_as_uint(Wv[2]), 0x80);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) t = __builtin_amdgcn_bitop3_b32(t, __float_as_uint(Wv[r]), __float_as_uint(Wv[r + 1]), 0x80);
+            t &= __float_as_uint(Wv[15]);
+            return !__any((int)t >= 0);
+        };
+        constexpr unsigned HB = 16u / RTW_SCAN_GROUP;       // mask bits per half block
         {
             rtw_f16v Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[0], zero, 0, 0, 0);
             Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[0], Wv, 0, 0, 0);
-            eval(Wv);
+#ifdef RTW_DUP_MFMA      // time probe: the half block's two MFMAs twice (same result)
+            __asm__ volatile("" : "+v"(Wv));
+            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[0], zero, 0, 0, 0);
+            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[0], Wv, 0, 0, 0);
+#endif
+#ifdef RTW_DUP_EVAL      // time probe: the sign collection twice
+            { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; }
+#endif
+            if (RTW_SCAN_SKIP && none(Wv)) mask = (1u << HB) - 1u;          // all negative
+            else eval(Wv);
         }
         {
             // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
             // padding at the end), so only one set of A registers is live during the evaluation
             rtw_f16v Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[1], zero, 0, 0, 0);
             Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[1], Wv, 0, 0, 0);
+#ifdef RTW_DUP_MFMA
+            __asm__ volatile("" : "+v"(Wv));
+            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[1], zero, 0, 0, 0);
+            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[1], Wv, 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];
             __builtin_amdgcn_sched_barrier(0);
-            eval(Wv);
+#ifdef RTW_DUP_EVAL
+            { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; }
+#endif
+            if (RTW_SCAN_SKIP && none(Wv)) mask = (mask << HB) | ((1u << HB) - 1u);
+            else eval(Wv);
         }
         clk.lap(2);
-        unsigned m = ~mask;                               // bit 31 - b: half wave b >> 4, result register b & 15
+        constexpr unsigned NB = 32u / RTW_SCAN_GROUP;     // list bits per block: bit NB - 1 - b, b = half wave << (4 | 2) | result register / group
+        unsigned m = ~mask;
+        if constexpr (NB < 32u) m &= (1u << NB) - 1u;
         if constexpr (!CULLED) {                          // (phase-profile build only: blocks, and blocks without any candidate)
             clk.count(7, 1u);
             if (!__any(m != 0u)) clk.count(6, 1u);
         }
-        const unsigned code0 = lane_const + (unsigned)blk * 32u + 31u;      // entry = recording lane << 16 | block << 5 | b
+        const unsigned code0 = lane_const + (unsigned)blk * 32u + (NB - 1u);      // entry = recording lane << 16 | block << 5 | b
 #ifdef RTW_DUP_EXTRACT   // instruction/time probe: the extraction loop twice (the first run writes the same entries)
-        { unsigned m2 = m, t2 = total;
+        { unsigned m2 = m, t2 = total;   // (probe)
           for (;;) {
               const unsigned long long act2 = __ballot(m2 != 0u);
               if (!act2 || t2 + 64u > RTW_PAIR_CAP) break;
