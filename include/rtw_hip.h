@@ -95,7 +95,7 @@ typedef struct {
                              named by `device`; N > 1 = the N ordinals in device_ids; -1 = every visible
                              device.  The 8x8 tiles are dealt round-robin to the devices (one host thread,
                              stream and PCIe link each); the image is identical for every device list.   */
-    int32_t job_pixels;   /* 0 = automatic.  1, 4 or 16: pixels per work-queue job (1x1, 2x2, 4x4 block).
+    int32_t job_pixels;   /* 0 = automatic.  1, 4, 8 or 16: pixels per work-queue job (1x1, 4x1, 8x1, 8x2: rows x columns).
                              Scheduling granularity only -- the image is identical for every value.      */
     const int32_t *device_ids; /* n_devices > 1: HIP ordinals; an ordinal may repeat (its shards then run
                              concurrently on that device)                                               */

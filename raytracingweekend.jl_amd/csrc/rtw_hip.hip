@@ -659,19 +659,22 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     // (Slots per workgroup: 24 / 12 / 4 -- one-pixel jobs need many slots in flight; with 6 they ran 33 % slower.)
     int job_shift = nch >= 16 ? 2 : 4;
     if (nch >= 64 && n_local * 16 < 150 * grid) job_shift = 0;
-    if (p->job_pixels == 16 || p->job_pixels == 4 || p->job_pixels == 1) {
-        job_shift = p->job_pixels == 16 ? 4 : p->job_pixels == 4 ? 2 : 0;
-    } else if (p->job_pixels != 0) {
-        return fail(-2, "job_pixels must be 0 (automatic), 1, 4 or 16");
+    static const int env_job_pixels = getenv("RTW_JOB_PIXELS") ? atoi(getenv("RTW_JOB_PIXELS")) : 0;      // measurement aid (tools/gpu_jobshape.sh)
+    const int job_pixels = p->job_pixels ? p->job_pixels : env_job_pixels;
+    if (job_pixels == 16 || job_pixels == 8 || job_pixels == 4 || job_pixels == 1) {
+        job_shift = job_pixels == 16 ? 4 : job_pixels == 8 ? 3 : job_pixels == 4 ? 2 : 0;
+    } else if (job_pixels != 0) {
+        return fail(-2, "job_pixels must be 0 (automatic), 1, 4, 8 or 16");
     }
     const long long total_jobs = n_local * (64 >> job_shift);
     const long long cpb = 64 >> job_shift;
     const long long bpj = (nch + cpb - 1) / cpb;
     if (total_jobs >= (1ll << 31) || total_jobs * bpj >= (1ll << 40))
         return fail(-5, "render too large for one call: %lld pixel-block jobs", total_jobs);
-    K.total_jobs = (unsigned)total_jobs; K.bpj = (unsigned)bpj; K.job_shift = (unsigned)job_shift;
+    K.total_jobs = (unsigned)total_jobs; K.local_tiles = (unsigned)n_local; K.bpj = (unsigned)bpj; K.job_shift = (unsigned)job_shift;
+    K.rows_shift = (unsigned)std::min(job_shift, 3);       // 4 x 1, 8 x 1, 8 x 2 pixels: whole column strips
     K.slot_stride = (unsigned)(sizeof(rtw::JobSlot) + 64u * (1u << job_shift));
-    K.n_slots = std::min(24u, (unsigned)RTW_SLOT_BYTES / K.slot_stride);             // 24 / 12 / 4 slots of 1 / 4 / 16 pixels
+    K.n_slots = std::min(24u, (unsigned)RTW_SLOT_BYTES / K.slot_stride);             // 24 / 12 / 7 / 4 slots of 1 / 4 / 8 / 16 pixels
     make_udiv(K.n_slots, &K.div_slots_m, &K.div_slots_s);
     make_udiv((unsigned)bpj, &K.div_bpj_m, &K.div_bpj_s);
     const long long max_useful = (total_jobs * bpj + 3) / 4;          // one batch per wave, 4 waves per block

@@ -22,8 +22,8 @@
 
 namespace rtw {
 
-#define RTW_JOB_PX 16        // slot capacity: pixels per job are 16 (4x4 block), 4 (2x2) or 1 -- KParams::job_shift
-#define RTW_SLOT_BYTES 4608  // LDS for job slots per workgroup: 24 slots of 1 pixel, 12 of 4 or 4 of 16
+#define RTW_JOB_PX 16        // slot capacity: pixels per job are 16 (8 rows x 2 columns), 8 (8 x 1), 4 (4 x 1) or 1 -- KParams::job_shift
+#define RTW_SLOT_BYTES 4608  // LDS for job slots per workgroup: 24 slots of 1 pixel, 12 of 4, 7 of 8 or 4 of 16
 #define RTW_REF_BITS 9       // item reference = slot (5 bits) << 4 | pixel (4 bits)
 #define RTW_REF_MASK 511u
 #define RTW_SLOT_FREE 0xffffffffu
@@ -37,11 +37,15 @@ struct KParams {
     int chunk_spp;
     int shard_index, shard_count;
     int tiles_i, tiles_j;  // 8x8 tiles along rows (i) and columns (j)
-    unsigned total_jobs;   // 4 * (tiles owned by this shard)
+    unsigned total_jobs;   // (64 >> job_shift) * (tiles owned by this shard)
+    unsigned local_tiles;  // tiles owned by this shard
     unsigned bpj;          // batches per job = ceil(n_chunks / (64 >> job_shift))
     unsigned n_slots, slot_stride, div_slots_m, div_slots_s;   // job slots per workgroup (by job size), bytes per slot, n / n_slots
-    unsigned job_shift;    // log2(pixels per job): 4, 2 or 0.  A batch = (1 << job_shift) pixels x (64 >> job_shift) chunks.
+    unsigned job_shift;    // log2(pixels per job): 4, 3, 2 or 0.  A batch = (1 << job_shift) pixels x (64 >> job_shift) chunks.
                            // Smaller jobs = finer load balance at the end of the queue (small shards); same image.
+    unsigned rows_shift;   // a job is (1 << rows_shift) rows x (1 << (job_shift - rows_shift)) columns: rows first, because rows are
+                           // contiguous in the column-major Matrix{RGB{T}} -- a finished job is stored as whole column strips
+                           // (pixel px of the job = row px & (rows - 1), column px >> rows_shift)
     // exact unsigned division by loop-invariant divisors (host: make_udiv):
     // n / d == (umulhi(n, m) + ((n - umulhi(n, m)) >> 1)) >> s   for every 32-bit n
     unsigned div_bpj_m, div_bpj_s, div_tiles_m, div_tiles_s;
@@ -50,8 +54,7 @@ struct KParams {
 };
 
 struct DevCounters {
-    unsigned next_job;
-    unsigned pad;
+    unsigned next_job[8];          // one job queue per XCD (claim_job)
     unsigned long long segments;
     unsigned long long samples;
     unsigned long long phase[8];   // RTW_PHASE_PROFILE=1 only: wave-cycles per phase (s_memtime)
@@ -70,16 +73,18 @@ struct JobSlot {
     int i_base, j_base;                      // 0-based row / column of the block's first pixel
     unsigned k_tile;                         // local tile index (compact output layout)
     unsigned pad;
-    double uv[8];                            // j / W for the block's columns, (H - i) / H for its rows (src/render.jl:26-27), as binary64
+    double uv[12];                           // [0..3] j / W for the block's columns, [4..11] (H - i) / H for its rows (src/render.jl:26-27), as binary64
     __device__ __forceinline__ unsigned long long *acc(unsigned px) { return reinterpret_cast<unsigned long long *>(this + 1) + 8u * px; }
     __device__ __forceinline__ const unsigned long long *acc(unsigned px) const { return reinterpret_cast<const unsigned long long *>(this + 1) + 8u * px; }
 };
-static_assert(sizeof(JobSlot) == 96, "JobSlot header is 96 bytes (16-byte aligned accumulators follow)");
+static_assert(sizeof(JobSlot) == 128, "JobSlot header is 128 bytes (16-byte aligned accumulators follow)");
+struct JobCache { unsigned long long jc; unsigned jc_lock; unsigned queue_off; unsigned last_g; unsigned pad; };       // see claim_job
 template <typename T> struct WgShared {
-    unsigned char slots[RTW_SLOT_BYTES];      // n_slots x (96-byte JobSlot + 64 bytes per job pixel)
+    unsigned char slots[RTW_SLOT_BYTES];      // n_slots x (128-byte JobSlot + 64 bytes per job pixel)
     __device__ __forceinline__ JobSlot *slot(unsigned i, unsigned stride) { return reinterpret_cast<JobSlot *>(slots + i * stride); }
     unsigned ticket;                         // next batch of this workgroup
     unsigned pad[3];
+    JobCache jobs;                           // queue positions claimed but not started yet (claim_job)
     Camera<T> cam;                           // read per new sample (keeps 22 SGPRs out of the scan loop)
     KParams P;                               // read where needed (item pull, store): not held in SGPRs across the scan
 };
@@ -173,10 +178,11 @@ __device__ __forceinline__ void fx_accumulate_channel(unsigned long long *acc, u
 // The store of one finished job (src/render.jl:40, src/vec.jl:22): lane = (pixel, channel).
 template <typename T>
 __device__ RTW_RARE_ATTR void store_job(const KParams &P, const JobSlot *S, unsigned lane, T *__restrict__ out) {
-    const unsigned px = lane & ((1u << P.job_shift) - 1u), ch = lane >> P.job_shift, side = P.job_shift >> 1;
-    if (ch < 3u) {
+    // lane = 3 * pixel + channel: consecutive lanes write consecutive elements of a column strip
+    const unsigned px = lane / 3u, ch = lane - 3u * px, rs = P.rows_shift;
+    if (px < (1u << P.job_shift)) {
         if ((S->valid >> px) & 1u) {
-            const int i0 = S->i_base + (int)(px & ((1u << side) - 1u)), j0 = S->j_base + (int)(px >> side);
+            const int i0 = S->i_base + (int)(px & ((1u << rs) - 1u)), j0 = S->j_base + (int)(px >> rs);
             const unsigned long long *a = S->acc(px);
             double v = fx_to_double(a[2 * ch], a[2 * ch + 1]);
             if (a[6] != 0ull) v = __builtin_nan("");
@@ -189,26 +195,127 @@ __device__ RTW_RARE_ATTR void store_job(const KParams &P, const JobSlot *S, unsi
     }
 }
 
-// Open a job slot (whole wave): take job ids from the global queue until one has a pixel inside the
-// image (or the queue is exhausted), zero its accumulators and fill in the block's header.
-__device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned lane, DevCounters *ctr) {
-    unsigned g, valid = 0, k = 0;
-    int i_base = 0, j_base = 0;
+// The XCD (one of the chip's 8 dies, each with its own L2) this wave runs on: HW_REG_XCC_ID[3:0].  Used for AFFINITY only --
+// any value in 0 .. 7 gives the same image.
+__device__ __forceinline__ unsigned xcd_id() { return (unsigned)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u; }
+
+// Job queues.  One queue per XCD: the image's 8x8 tiles are dealt to the queues so that all jobs writing the same 128-byte
+// lines of the frame are taken by workgroups of ONE die -- its write-back L2 then merges their 24-byte pieces and every line
+// goes to HBM once, whole (a single global queue spread each tile's 16 jobs over all eight L2s: partial-line writes, 2.7 x the
+// frame's bytes in WRITE_SIZE).  Full frame (shard_count == 1): tile-column tj (8 pixel columns = one contiguous 8 H RGB{T}
+// strip of the column-major Matrix{RGB{T}}) belongs to queue tj mod 8 -- only the first and last line of a strip are shared with
+// a neighbour queue.  Sharded / compact: local tile k belongs to queue k mod 8 (a compact tile is 6 whole lines of its own).
+// A workgroup takes from its own die's queue and, when that is exhausted, from the next ones (the tail of the frame).
+__device__ __forceinline__ unsigned queue_tiles(const KParams &P, unsigned xq) {
+    if (P.shard_count == 1) { const unsigned tj = (unsigned)P.tiles_j; return tj > xq ? ((tj - xq + 7u) >> 3) * (unsigned)P.tiles_i : 0u; }
+    return P.local_tiles > xq ? (P.local_tiles - xq + 7u) >> 3 : 0u;
+}
+
+// One claim from the job queues (lane 0 of the wave that opens a slot).  A global atomic is a 32-byte write (and read) at
+// the memory side -- whatever its scope: this memory is write-through in the L2 and "workgroup"-scope atomics on a line that only
+// one die touches went to HBM just the same (measured: a two-level queue with die-local second-level counters TRIPLED
+// WRITE_SIZE) -- and one per 4-pixel job was 16.6 MB per 1080p frame, two thirds of the frame itself.  So a workgroup claims
+// RTW_JOB_CLAIM consecutive queue positions with ONE atomic and hands the others out from LDS (`jc`: queue << 56 | end << 28 |
+// next; `jc_lock` serialises refills, a wave that does not get the lock claims a single position).  Consecutive positions
+// are the same sub-block of tiles FAR APART in the frame (job_of_position), not neighbouring jobs: neighbours cost alike (the
+// glass sphere of the headline scene spans 76 tiles), and a workgroup that holds eight expensive jobs at once falls behind --
+// +2 ms of end-of-queue drain per job claimed together, measured -- while neighbouring strips of the frame are still
+// written at about the same time by workgroups of one die, which is what lets its L2 merge them into whole 32-byte sectors.
+// Another die's queue is only ever visited at its end: single claims there.  Returns false when every queue is exhausted.
+#ifndef RTW_JOB_CLAIM
+#define RTW_JOB_CLAIM 8u
+#endif
+#ifndef RTW_CLAIM_TAIL
+#define RTW_CLAIM_TAIL 4u      // single claims once fewer than RTW_JOB_CLAIM x this many positions per workgroup of the die are left
+#endif
+static_assert(RTW_JOB_CLAIM == 1u || RTW_JOB_CLAIM == 2u || RTW_JOB_CLAIM == 4u || RTW_JOB_CLAIM == 8u || RTW_JOB_CLAIM == 16u, "power of two");
+// queue position -> (tile within the queue, sub-block).  The queue's tiles are cut into RTW_JOB_CLAIM equal STREAMS (stream k =
+// tiles [k S, (k + 1) S), S = ceil(tiles / RTW_JOB_CLAIM)); position = (step << (CS + sub_shift)) | sub-block << CS | stream:
+// the RTW_JOB_CLAIM positions of one claim are the same sub-block of tile `step` of every stream -- far apart in the frame.
+// A bijection onto [0, S x RTW_JOB_CLAIM x subs); tiles beyond the queue's last (the padding of the last stream) do not exist
+// and are skipped like blocks outside the image.
+__device__ __forceinline__ unsigned queue_stream_len(const KParams &P, unsigned xq) { return (queue_tiles(P, xq) + RTW_JOB_CLAIM - 1u) / RTW_JOB_CLAIM; }
+__device__ __forceinline__ void job_of_position(unsigned pos, unsigned sub_shift, unsigned stream_len, unsigned &qt, unsigned &q) {
+    constexpr unsigned CS = RTW_JOB_CLAIM == 1u ? 0u : RTW_JOB_CLAIM == 2u ? 1u : RTW_JOB_CLAIM == 4u ? 2u : RTW_JOB_CLAIM == 8u ? 3u : 4u;
+    const unsigned step = pos >> (CS + sub_shift), c = pos & ((1u << (CS + sub_shift)) - 1u);
+    qt = (c & (RTW_JOB_CLAIM - 1u)) * stream_len + step;
+    q = c >> CS;
+}
+__device__ __forceinline__ unsigned queue_positions(const KParams &P, unsigned xq, unsigned sub_shift) {
+    return (queue_stream_len(P, xq) * RTW_JOB_CLAIM) << sub_shift;
+}
+__device__ __forceinline__ bool claim_job(const KParams &P, DevCounters *ctr, JobCache *C, unsigned xcd, unsigned sub_shift, unsigned &xq_out, unsigned &gq_out) {
+    constexpr unsigned long long M28 = (1ull << 28) - 1ull;
     for (;;) {
-        g = 0;
-        if (lane == 0) g = atomicAdd(&ctr->next_job, 1u);
-        g = uniform(g);
-        if (g >= P.total_jobs) { g = RTW_JOB_EOF; break; }
-        const unsigned side = P.job_shift >> 1, sub_shift = 6u - P.job_shift, bps_shift = 3u - side;
-        k = g >> sub_shift;                                  // job = (local tile) * (blocks per tile) + block
-        const unsigned q = g & ((1u << sub_shift) - 1u);
-        const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
-        const unsigned tj = udiv_magic(t, P.div_tiles_m, P.div_tiles_s), ti = t - tj * (unsigned)P.tiles_i;
-        i_base = (int)(ti * 8u + ((q & ((1u << bps_shift) - 1u)) << side));
-        j_base = (int)(tj * 8u + ((q >> bps_shift) << side));
-        const int i0 = i_base + (int)(lane & ((1u << side) - 1u)), j0 = j_base + (int)((lane >> side) & ((1u << side) - 1u));
+        unsigned long long w = __hip_atomic_load(&C->jc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while ((w & M28) < ((w >> 28) & M28)) {                    // cached positions: take one
+            if (__hip_atomic_compare_exchange_strong(&C->jc, &w, w + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                xq_out = (unsigned)(w >> 56); gq_out = (unsigned)(w & M28);
+                return true;
+            }
+        }
+        unsigned expect = 0u;
+        const bool locked = __hip_atomic_compare_exchange_strong(&C->jc_lock, &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (locked) {
+            w = __hip_atomic_load(&C->jc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((w & M28) < ((w >> 28) & M28)) {                   // refilled by the previous lock holder meanwhile: use that
+                __hip_atomic_store(&C->jc_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+            }
+        }
+        unsigned off = __hip_atomic_load(&C->queue_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bool got = false;
+        while (off < 8u) {
+            const unsigned xq = (xcd + off) & 7u;
+            const unsigned q_pos = queue_positions(P, xq, sub_shift);
+            // several positions per claim only while plenty is left for everybody (what this workgroup's previous claim returned
+            // tells how far the queue is; the other workgroups of the die claim about as much in between)
+            const unsigned seen = C->last_g, left = q_pos > seen ? q_pos - seen : 0u;
+            const unsigned n = (locked && off == 0u && left > RTW_JOB_CLAIM * RTW_CLAIM_TAIL * (gridDim.x / 8u + 1u)) ? RTW_JOB_CLAIM : 1u;
+            const unsigned g0 = atomicAdd(&ctr->next_job[xq], n);
+            if (off == 0u) C->last_g = g0;
+            if (g0 >= q_pos) { off += 1u; continue; }            // this queue is exhausted (for good): the next die's
+            xq_out = xq; gq_out = g0; got = true;
+            const unsigned end = g0 + n < q_pos ? g0 + n : q_pos;
+            if (locked && end > g0 + 1u)
+                __hip_atomic_store(&C->jc, ((unsigned long long)xq << 56) | ((unsigned long long)end << 28) | (unsigned long long)(g0 + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
+        __hip_atomic_store(&C->queue_off, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (locked) __hip_atomic_store(&C->jc_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return got;
+    }
+}
+
+// Open a job slot (whole wave): take job ids from the queues until one has a pixel inside the
+// image (or every queue is exhausted), zero its accumulators and fill in the block's header.
+__device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned lane, DevCounters *ctr, JobCache *jcache) {
+    unsigned g = RTW_JOB_EOF, valid = 0, k = 0;
+    int i_base = 0, j_base = 0;
+    const unsigned rs = P.rows_shift, cs = P.job_shift - rs, sub_shift = 6u - P.job_shift, bps_shift = 3u - rs;
+    const unsigned xcd = xcd_id();
+    for (;;) {
+        unsigned xq = 0, gq = 0, ok = 0;
+        if (lane == 0) ok = claim_job(P, ctr, jcache, xcd, sub_shift, xq, gq) ? 1u : 0u;
+        if (!uniform(ok)) break;
+        xq = uniform(xq); gq = uniform(gq);
+        unsigned qt, q, tj, ti;                                  // tile within the queue, block within the tile
+        job_of_position(gq, sub_shift, queue_stream_len(P, xq), qt, q);
+        if (qt >= queue_tiles(P, xq)) continue;                  // (padding of the queue's last stream)
+        if (P.shard_count == 1) {
+            const unsigned tjq = udiv_magic(qt, P.div_tiles_m, P.div_tiles_s);
+            ti = qt - tjq * (unsigned)P.tiles_i; tj = xq + 8u * tjq;
+            k = tj * (unsigned)P.tiles_i + ti;
+        } else {
+            k = xq + 8u * qt;
+            const unsigned t = k * (unsigned)P.shard_count + (unsigned)P.shard_index;
+            tj = udiv_magic(t, P.div_tiles_m, P.div_tiles_s); ti = t - tj * (unsigned)P.tiles_i;
+        }
+        i_base = (int)(ti * 8u + ((q & ((1u << bps_shift) - 1u)) << rs));
+        j_base = (int)(tj * 8u + ((q >> bps_shift) << cs));
+        const int i0 = i_base + (int)(lane & ((1u << rs) - 1u)), j0 = j_base + (int)((lane >> rs) & ((1u << cs) - 1u));
         valid = (unsigned)__ballot(lane < (1u << P.job_shift) && i0 < P.height && j0 < P.width);
-        if (valid) break;                                    // (blocks entirely outside the image are skipped)
+        if (valid) { g = gq; break; }                            // (blocks entirely outside the image are skipped)
     }
     if (g != RTW_JOB_EOF) {
         if (lane < (4u << P.job_shift)) {
@@ -217,7 +324,7 @@ __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned la
             reinterpret_cast<uint4 *>(S->acc(0))[lane] = uint4{zero, zero, zero, zero};   // 64 B per pixel
         }
         if (lane < 4) S->uv[lane] = (double)(j_base + (int)lane + 1) / (double)P.width;                        // j / W
-        else if (lane < 8) S->uv[lane] = (double)(P.height - (i_base + (int)lane - 4 + 1)) / (double)P.height;   // (H - i) / H
+        else if (lane < 12) S->uv[lane] = (double)(P.height - (i_base + (int)lane - 4 + 1)) / (double)P.height;   // (H - i) / H
         if (lane == 0) {
             S->remaining = (int)((unsigned)__popc(valid) * (unsigned)P.n_chunks);
             S->valid = valid; S->i_base = i_base; S->j_base = j_base; S->k_tile = k;
@@ -253,7 +360,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
     }
     unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + (CULL ? cull_exact_count(cull) : 0));
     if (threadIdx.x < P_arg.n_slots) { JobSlot *S0 = sh->slot(threadIdx.x, P_arg.slot_stride); S0->ready_seq = RTW_SLOT_FREE; S0->job = 0u; }
-    if (threadIdx.x == 0) { sh->ticket = 0u; sh->cam = cam_arg; sh->P = P_arg; }
+    if (threadIdx.x == 0) { sh->ticket = 0u; sh->jobs.jc = 0ull; sh->jobs.jc_lock = 0u; sh->jobs.queue_off = 0u; sh->jobs.last_g = 0u; sh->cam = cam_arg; sh->P = P_arg; }
     const KParams &P = sh->P;
     if (LDS_SCENE) {
         if (CULL) stage_cull_scene<T>(cull, lds_geom, lds_orig);
@@ -393,7 +500,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
                     }
                     if (uniform(won)) {
-                        open_job(P, S, lane, ctr);
+                        open_job(P, S, lane, ctr, &sh->jobs);
                         __hip_atomic_store(&S->ready_seq, tk_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         rs = tk_seq;
                     }
@@ -411,8 +518,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                             // Lane l prepares item l of the batch: setting up a stream is 2 splitmix64 + 1 step (~60 VALU), and a
                             // wave takes items a few lanes at a time -- almost every iteration for ~6 % of its lanes.
                             const unsigned px = lane & ((1u << P.job_shift) - 1u), chunk = tk_b * (64u >> P.job_shift) + (lane >> P.job_shift);
-                            const unsigned side = P.job_shift >> 1;
-                            const int i0 = S->i_base + (int)(px & ((1u << side) - 1u)), j0 = S->j_base + (int)(px >> side);
+                            const unsigned rs = P.rows_shift;
+                            const int i0 = S->i_base + (int)(px & ((1u << rs) - 1u)), j0 = S->j_base + (int)(px >> rs);
                             Rng r0;
                             rng_stream(P.seed, (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0, chunk, r0);
                             pool_rng[lane] = ulonglong2{r0.x, r0.y};
@@ -438,8 +545,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                             const ulonglong2 st = pool_rng[p];
                             rng.x = st.x; rng.y = st.y;
                         } else {
-                            const unsigned side = P.job_shift >> 1;
-                            const int i0 = S->i_base + (int)(px & ((1u << side) - 1u)), j0 = S->j_base + (int)(px >> side);
+                            const unsigned rs = P.rows_shift;
+                            const int i0 = S->i_base + (int)(px & ((1u << rs) - 1u)), j0 = S->j_base + (int)(px >> rs);
                             const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
                             rng_stream(P.seed, pix, chunk, rng);
                         }
@@ -490,9 +597,9 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             }
             const JobSlot *S = sh->slot((ref_depth & RTW_REF_MASK) >> 4, P.slot_stride);
             const unsigned px = ref_depth & 15u;
-            const unsigned side = P.job_shift >> 1;
-            su = (T)S->uv[px >> side] + du;                            // T(j / W) + du,       src/render.jl:26,37
-            sv = (T)S->uv[4 + (px & ((1u << side) - 1u))] + dv;        // T((H - i) / H) + dv, src/render.jl:27,37
+            const unsigned rs = P.rows_shift;
+            su = (T)S->uv[px >> rs] + du;                              // T(j / W) + du,       src/render.jl:26,37
+            sv = (T)S->uv[4 + (px & ((1u << rs) - 1u))] + dv;          // T((H - i) / H) + dv, src/render.jl:27,37
             new_sample = true;
             jitter = true;
             samples_left -= 1;

@@ -235,10 +235,10 @@ def test_exact_accumulation_unit(oracle):
 
 @pytest.mark.parametrize("name", ["cfg2_random_320x180_64spp_d16_f32", "random_64x36_8spp_d50_f64", "metal4_96x54_8spp_d16_f32"])
 def test_job_size_does_not_change_the_image(name):
-    """rtw_params.job_pixels (1, 4 or 16 pixels per work-queue job; 0 = automatic) is scheduling
-    granularity only: same image, same segment count, also for a shard and in group-cull mode"""
+    """rtw_params.job_pixels (1, 4, 8 or 16 pixels per work-queue job: column strips of 1x1, 4x1, 8x1, 8x2 rows x columns;
+    0 = automatic) is scheduling granularity only: same image, same segment count, also for a shard and in group-cull mode"""
     g = load_golden(name)
-    for jp in (1, 4, 16):
+    for jp in (1, 4, 8, 16):
         img, st = gpu_render(g, job_pixels=jp)
         assert np.array_equal(img, g["image"]) and st.segments == g["segments"], jp
     a, _ = gpu_render(g, job_pixels=1, shard_index=1, shard_count=5, flags=1)
@@ -248,7 +248,8 @@ def test_job_size_does_not_change_the_image(name):
     w = 50
     x, _ = gpu_render(g, width=w, height=(w * 9) // 16, spp=5, n_chunks=5, job_pixels=1)
     y, _ = gpu_render(g, width=w, height=(w * 9) // 16, spp=5, n_chunks=5, job_pixels=16)
-    assert np.array_equal(x, y)
+    z, _ = gpu_render(g, width=w, height=(w * 9) // 16, spp=5, n_chunks=5, job_pixels=8)
+    assert np.array_equal(x, y) and np.array_equal(x, z)
 
 
 def test_image_is_invariant_under_chunk_order_and_slots(oracle, rtw):
