@@ -93,8 +93,9 @@ typedef struct {
     int32_t flags;        /* 0, or RTW_FLAG_* (opt-in modes; the image is identical in every mode)    */
     int32_t n_devices;    /* rtw_render_f32/_f64 only (Julia keyword `devices`): 0 or 1 = the one device
                              named by `device`; N > 1 = the N ordinals in device_ids; -1 = every visible
-                             device.  The 8x8 tiles are dealt round-robin to the devices (one host thread,
-                             stream and PCIe link each); the image is identical for every device list.   */
+                             device.  The 8x8 tiles are dealt round-robin to the devices (a stream each); the
+                             shards are gathered in HBM of the first device of the list (peer copies over xGMI)
+                             and the frame is copied to `out` once.  The image is identical for every device list. */
     int32_t job_pixels;   /* 0 = automatic.  1, 4, 8 or 16: pixels per work-queue job (1x1, 4x1, 8x1, 8x2: rows x columns).
                              Scheduling granularity only -- the image is identical for every value.      */
     const int32_t *device_ids; /* n_devices > 1: HIP ordinals; an ordinal may repeat (its shards then run
@@ -122,7 +123,10 @@ const char *rtw_last_error(void);
 /* render(scene, cam, width, spp) for elem_type Float32 / Float64 -- replaces
  * /root/reference/src/render.jl:8-44.  `out` is a HOST buffer of height*width*3 elements in
  * the memory layout of the returned Matrix{RGB{T}}: pixel (i,j) (1-based row, column) at
- * ((j-1)*height + (i-1))*3.  Blocking.  Uploads the scene, renders, copies the image back. */
+ * ((j-1)*height + (i-1))*3.  Blocking.  Uploads the scene, renders, copies the image back.
+ * The library keeps the uploaded scene (recognised by its bytes), a stream and the device image per
+ * device between calls: from the second call of a scene on, a call costs its kernel + one D2H of the
+ * image (0.5 ms at 1920x1080 Float32).  rtw_shutdown() releases them. */
 int rtw_render_f32(const rtw_scene_f32 *scene, const rtw_camera_f32 *cam, const rtw_params *p,
                    float *out);
 int rtw_render_f64(const rtw_scene_f64 *scene, const rtw_camera_f64 *cam, const rtw_params *p,
