@@ -252,6 +252,19 @@ void kd_split(const SceneT *s, std::vector<int> &ids, int lo, int hi, std::vecto
     kd_split(s, ids, lo + half, hi, groups);
 }
 
+// the cold per-sphere rows (rtw_device.hpp "device scene"): mat0 = (r, param, kind, 1 / ir), mat1 = albedo -- or, for a Dielectric,
+// Schlick's r0 for a front and a back face (dielectric_constants: the reference's own expressions evaluated once, in T)
+template <typename T, typename V4, typename SceneT>
+void material_rows(const SceneT *s, int i, V4 &m0, V4 &m1) {
+    m0 = V4{s->r[i], s->param[i], (T)s->kind[i], (T)0};
+    m1 = V4{s->ar[i], s->ag[i], s->ab[i], (T)0};
+    if (s->kind[i] == rtw::DIELECTRIC) {
+        const rtw::DielConst<T> c = rtw::dielectric_constants<T>(s->param[i]);
+        m0.w = c.inv_ir;
+        m1 = V4{c.r0_front, c.r0_back, (T)0, (T)0};
+    }
+}
+
 // cluster-major arrays for the opt-in group-cull scan (rtw_device.hpp, "opt-in accelerated scan")
 template <typename T, typename V4>
 int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, void **ops_out, int *blocks_out);
@@ -286,8 +299,7 @@ int build_cull(const SceneT *s, rtw_scene_dev *h) {
     for (int k = 0; k < n_exact; ++k) { exact[k] = V4{(T)0, (T)0, (T)0, (T)-1e30}; mat0[k] = V4{(T)1, (T)0, (T)0, (T)0}; mat1[k] = V4{(T)0, (T)0, (T)0, (T)0}; }
     auto put = [&](int k, int i) {
         exact[k] = V4{s->cx[i], s->cy[i], s->cz[i], s->r[i] * s->r[i]};
-        mat0[k] = V4{s->r[i], s->param[i], (T)s->kind[i], (T)0};
-        mat1[k] = V4{s->ar[i], s->ag[i], s->ab[i], (T)0};
+        material_rows<T, V4>(s, i, mat0[k], mat1[k]);
         orig[k] = (unsigned short)i;
     };
     double cs[3] = {0, 0, 0}, rs = 0;
@@ -495,8 +507,7 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
     for (int i = 0; i < n_alloc; ++i) {
         if (i < n) {
             geom[i] = V4{s->cx[i], s->cy[i], s->cz[i], s->r[i] * s->r[i]};  // r^2: src/hit.jl:17
-            mat0[i] = V4{s->r[i], s->param[i], (T)s->kind[i], (T)0};
-            mat1[i] = V4{s->ar[i], s->ag[i], s->ab[i], (T)0};
+            material_rows<T, V4>(s, i, mat0[i], mat1[i]);
         } else {
             // padding sphere that can never be hit: r^2 hugely negative => disc < 0 always
             geom[i] = V4{(T)0, (T)0, (T)0, (T)-1e30};
@@ -940,6 +951,8 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
         if (my_bytes == 0) continue;
         void *d_out = slot;
         if (hc->device != root->device) {
+            const hipError_t e0 = hipSetDevice(hc->device);               // (the shard buffer belongs to ITS device)
+            if (e0 != hipSuccess) { rc = fail((int)e0, "hipSetDevice(%d): %s", hc->device, hipGetErrorString(e0)); break; }
             if ((rc = ensure_dev(&hc->d_img, &hc->d_cap, my_bytes))) break;
             d_out = hc->d_img;
         }

@@ -576,7 +576,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             HitRec<T> rec;
             make_hitrec<T>({g.x, g.y, g.z}, m0.x, ro, rd, t_hit, rec);
             kind = (int)m0.z;
-            todo = scatter_begin<T>(rng, kind, m0.y, rd, rec, vec, vscale_);
+            const DielConst<T> dc = {m0.w, m1.x, m1.y};
+            todo = scatter_begin<T>(rng, kind, m0.y, rd, rec, vec, vscale_, &dc);
             const V3<T> att = attenuation_of<T>(kind, {m1.x, m1.y, m1.z});
             thr_r = thr_r * (double)att.x; thr_g = thr_g * (double)att.y; thr_b = thr_b * (double)att.z;
             ro = rec.p;
