@@ -23,7 +23,9 @@
 namespace rtw {
 
 #define RTW_JOB_PX 16        // slot capacity: pixels per job are 16 (8 rows x 2 columns), 8 (8 x 1), 4 (4 x 1) or 1 -- KParams::job_shift
+#ifndef RTW_SLOT_BYTES
 #define RTW_SLOT_BYTES 4608  // LDS for job slots per workgroup: 24 slots of 1 pixel, 12 of 4, 7 of 8 or 4 of 16
+#endif
 #define RTW_REF_BITS 9       // item reference = slot (5 bits) << 4 | pixel (4 bits)
 #define RTW_REF_MASK 511u
 #define RTW_SLOT_FREE 0xffffffffu
