@@ -658,8 +658,8 @@ __device__ __forceinline__ double lane_get(double v, unsigned src_lane) {
 #endif
 static_assert(RTW_SCAN_GROUP == 1 || RTW_SCAN_GROUP == 4, "groups of 1 or 4 result registers");
 #ifndef RTW_SCAN_SKIP
-#define RTW_SCAN_SKIP 0      // 1: wave-level early-out per half block (hit_world_mfma).  Measured: no gain (84.2 vs 84.8 ms at 200 spp) --
-                             // the compiler if-converts it, and the sign collection it would skip costs 13 % of the kernel in all
+#define RTW_SCAN_SKIP 1      // wave-level early-out per half block (hit_world_mfma): 372.2 vs 376.3 ms.  (Left to the compiler it is
+                             // if-converted -- both sides executed -- and gains nothing: the sign collection's side is fenced by an asm.)
 #endif
 
 // Walk n entries of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
@@ -823,6 +823,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             }
         }
         unsigned mask = 0;
+        bool any_cand = false;                               // (wave-uniform)
         const rtw_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         auto eval = [&](const rtw_f16v &Wv) {
             if constexpr (RTW_SCAN_GROUP == 1) {
@@ -858,10 +859,10 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[0], Wv, 0, 0, 0);
 #endif
 #ifdef RTW_DUP_EVAL      // time probe: the sign collection twice
-            { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; }
+            { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
 #endif
             if (RTW_SCAN_SKIP && none(Wv)) mask = (1u << HB) - 1u;          // all negative
-            else eval(Wv);
+            else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }      // (the asm keeps it a real branch: no if-conversion)
         }
         {
             // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
@@ -877,12 +878,16 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];
             __builtin_amdgcn_sched_barrier(0);
 #ifdef RTW_DUP_EVAL
-            { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; }
+            { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
 #endif
             if (RTW_SCAN_SKIP && none(Wv)) mask = (mask << HB) | ((1u << HB) - 1u);
-            else eval(Wv);
+            else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }
         }
         clk.lap(2);
+        if (RTW_SCAN_SKIP && !any_cand) {                    // no lane has a candidate in this block: nothing to extract
+            if constexpr (!CULLED) { clk.count(7, 1u); clk.count(6, 1u); }
+            continue;
+        }
         constexpr unsigned NB = 32u / RTW_SCAN_GROUP;     // list bits per block: bit NB - 1 - b, b = half wave << (4 | 2) | result register / group
         unsigned m = ~mask;
         if constexpr (NB < 32u) m &= (1u << NB) - 1u;
