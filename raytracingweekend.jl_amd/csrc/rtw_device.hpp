@@ -651,12 +651,13 @@ __device__ __forceinline__ double lane_get(double v, unsigned src_lane) {
 // bits of a group's filter values are ANDed with fast-class bit operations (v_bitop3_b32 / v_and_b32: 2.4 cycles) and only
 // the group's bit goes through the slow-class v_alignbit_b32 (4.3 cycles) -- 16 + 8 instead of 32 instructions per block of
 // 32 spheres; pass 2 applies the exact test to every member of a flagged group.  1 (default): one sphere per list entry.
-// Measured (1080p x 1000 spp Float32, same box): groups of 4 378.3 ms, single spheres 372.6 ms -- the slow-class alignbits
-// already pair with other waves' FMA-class instructions, and pass 2 pays four exact tests per entry.  Kept for A/B runs.
+// Measured (1080p x 1000 spp Float32, same box, with the wave-level early-out): single spheres 370.9 ms, groups of 2 380.5,
+// of 4 388.0 -- pass 2 pays one exact test (sqrt, root selection, LDS atomic) per member of a flagged group, more than the
+// alignbits saved.  Kept for A/B runs.
 #ifndef RTW_SCAN_GROUP
 #define RTW_SCAN_GROUP 1
 #endif
-static_assert(RTW_SCAN_GROUP == 1 || RTW_SCAN_GROUP == 4, "groups of 1 or 4 result registers");
+static_assert(RTW_SCAN_GROUP == 1 || RTW_SCAN_GROUP == 2 || RTW_SCAN_GROUP == 4, "groups of 1, 2 or 4 result registers");
 #ifndef RTW_SCAN_SKIP
 #define RTW_SCAN_SKIP 1      // wave-level early-out per half block (hit_world_mfma): 372.2 vs 376.3 ms.  (Left to the compiler it is
                              // if-converted -- both sides executed -- and gains nothing: the sign collection's side is fenced by an asm.)
@@ -675,9 +676,10 @@ __device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin,
         const bool valid = p < n;
         const unsigned e = ws.pairs[valid ? p : 0u];
         // entry = recording lane (H, j) << 16 | block << 5 | b.   G = 1: b = half << 4 | result register: ray j + 32 (b >> 4), sphere
-        // 32 block + 16 H + (b & 15).   G = 4: b = half << 2 | group: ray j + 32 (b >> 2), spheres 32 block + 16 H + 4 (b & 3) + 0..3
+        // 32 block + 16 H + (b & 15).   G = 2 / 4: b = half << (3 / 2) | group: ray j + 32 half, spheres 32 block + 16 H + G group + 0..G-1
         unsigned owner, sph0;
         if constexpr (G == 1) { owner = ((e >> 16) & 31u) + ((e & 16u) << 1); sph0 = (e & 0xffefu) + ((e >> 17) & 16u); }
+        else if constexpr (G == 2) { owner = ((e >> 16) & 31u) + ((e & 8u) << 2); sph0 = (e & 0xffe0u) + ((e >> 17) & 16u) + ((e & 7u) << 1); }
         else { owner = ((e >> 16) & 31u) + ((e & 4u) << 3); sph0 = (e & 0xffe0u) + ((e >> 17) & 16u) + ((e & 3u) << 2); }
         const V3<T> po = {lane_get(o.x, owner), lane_get(o.y, owner), lane_get(o.z, owner)};
         const V3<T> pd = {lane_get(d.x, owner), lane_get(d.y, owner), lane_get(d.z, owner)};
@@ -829,6 +831,9 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             if constexpr (RTW_SCAN_GROUP == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]), 31);
+            } else if constexpr (RTW_SCAN_GROUP == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]) & __float_as_uint(Wv[r + 1]), 31);
             } else {
                 // sign of (a & b & c & d) is set iff all four filter values are negative: no member is a candidate
 #pragma unroll
