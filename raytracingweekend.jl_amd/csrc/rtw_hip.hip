@@ -684,6 +684,8 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
         return fail(-5, "render too large for one call: %lld pixel-block jobs", total_jobs);
     K.total_jobs = (unsigned)total_jobs; K.local_tiles = (unsigned)n_local; K.bpj = (unsigned)bpj; K.job_shift = (unsigned)job_shift;
     K.rows_shift = (unsigned)std::min(job_shift, 3);       // 4 x 1, 8 x 1, 8 x 2 pixels: whole column strips
+    static const int env_rows_shift = getenv("RTW_ROWS_SHIFT") ? atoi(getenv("RTW_ROWS_SHIFT")) : -1;             // measurement aid: job shape
+    if (env_rows_shift >= 0 && env_rows_shift <= job_shift && env_rows_shift <= 3 && job_shift - env_rows_shift <= 2) K.rows_shift = (unsigned)env_rows_shift;
     K.slot_stride = (unsigned)(sizeof(rtw::JobSlot) + 64u * (1u << job_shift));
     K.n_slots = std::min(24u, (unsigned)RTW_SLOT_BYTES / K.slot_stride);             // 24 / 12 / 7 / 4 slots of 1 / 4 / 8 / 16 pixels
     make_udiv(K.n_slots, &K.div_slots_m, &K.div_slots_s);

@@ -201,51 +201,42 @@ __device__ RTW_RARE_ATTR void store_job(const KParams &P, const JobSlot *S, unsi
 // any value in 0 .. 7 gives the same image.
 __device__ __forceinline__ unsigned xcd_id() { return (unsigned)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u; }
 
-// Job queues.  One queue per XCD: the image's 8x8 tiles are dealt to the queues so that all jobs writing the same 128-byte
-// lines of the frame are taken by workgroups of ONE die -- its write-back L2 then merges their 24-byte pieces and every line
-// goes to HBM once, whole (a single global queue spread each tile's 16 jobs over all eight L2s: partial-line writes, 2.7 x the
-// frame's bytes in WRITE_SIZE).  Full frame (shard_count == 1): tile-column tj (8 pixel columns = one contiguous 8 H RGB{T}
-// strip of the column-major Matrix{RGB{T}}) belongs to queue tj mod 8 -- only the first and last line of a strip are shared with
-// a neighbour queue.  Sharded / compact: local tile k belongs to queue k mod 8 (a compact tile is 6 whole lines of its own).
-// A workgroup takes from its own die's queue and, when that is exhausted, from the next ones (the tail of the frame).
+// Job queues.  One queue per XCD (one of the chip's 8 dies, each with its own L2), a workgroup's home queue being its own die's:
+// full frame (shard_count == 1): tile-column tj (8 pixel columns = one contiguous 8 H RGB{T} strip of the column-major
+// Matrix{RGB{T}}) belongs to queue tj mod 8; sharded / compact: local tile k belongs to queue k mod 8.  A queue's positions are
+// tile-major (position = tile within the queue x sub-blocks per tile + sub-block), so a die works its way through a tile column
+// from the top, and the jobs in flight on the chip at any time are neighbours in the frame: measured, that is worth 1 % of
+// the frame time (rays of neighbouring pixels share the blocks of spheres the wave-level early-out of the scan can skip:
+// with the queue cut into 8 far-apart streams, taken in turn, the same kernel ran 364.3 ms instead of 361.5), and what the
+// frame's write traffic needs: neighbouring 48-byte strips are stored at about the same time and leave the L2 as whole sectors.
+// A workgroup takes from its home queue and, when that is exhausted, from the next ones (the tail of the frame).
 __device__ __forceinline__ unsigned queue_tiles(const KParams &P, unsigned xq) {
     if (P.shard_count == 1) { const unsigned tj = (unsigned)P.tiles_j; return tj > xq ? ((tj - xq + 7u) >> 3) * (unsigned)P.tiles_i : 0u; }
     return P.local_tiles > xq ? (P.local_tiles - xq + 7u) >> 3 : 0u;
 }
+__device__ __forceinline__ unsigned queue_positions(const KParams &P, unsigned xq, unsigned sub_shift) { return queue_tiles(P, xq) << sub_shift; }
 
 // One claim from the job queues (lane 0 of the wave that opens a slot).  A global atomic is a 32-byte write (and read) at
 // the memory side -- whatever its scope: this memory is write-through in the L2 and "workgroup"-scope atomics on a line that only
 // one die touches went to HBM just the same (measured: a two-level queue with die-local second-level counters TRIPLED
-// WRITE_SIZE) -- and one per 4-pixel job was 16.6 MB per 1080p frame, two thirds of the frame itself.  So a workgroup claims
-// RTW_JOB_CLAIM consecutive queue positions with ONE atomic and hands the others out from LDS (`jc`: queue << 56 | end << 28 |
-// next; `jc_lock` serialises refills, a wave that does not get the lock claims a single position).  Consecutive positions
-// are the same sub-block of tiles FAR APART in the frame (job_of_position), not neighbouring jobs: neighbours cost alike (the
-// glass sphere of the headline scene spans 76 tiles), and a workgroup that holds eight expensive jobs at once falls behind --
-// +2 ms of end-of-queue drain per job claimed together, measured -- while neighbouring strips of the frame are still
-// written at about the same time by workgroups of one die, which is what lets its L2 merge them into whole 32-byte sectors.
+// WRITE_SIZE) -- and one per 4-pixel job was 16.6 MB per 1080p frame, two thirds of the frame itself.  So a workgroup claims up
+// to RTW_JOB_CLAIM consecutive queue positions -- neighbouring strips of one tile -- with ONE atomic and hands the others out
+// from LDS (`jc`: queue << 56 | end << 28 | next; `jc_lock` serialises refills, a wave that does not get the lock claims a
+// single position).  What a workgroup holds nobody else can take, and neighbours cost alike (the glass sphere of the headline
+// scene spans 76 tiles: a workgroup there starts a job every 4 ms, not every 0.9): a fixed 8 per claim left 17 ms of idle wave
+// slots at the end of the frame.  Hence guided self-scheduling: a claim takes left / (RTW_CLAIM_TAIL x workgroups of the
+// die) positions, at most RTW_JOB_CLAIM -- 8 for the first two thirds of the queue, then 7, 6 ... 1 -- where `left` is
+// what this workgroup's previous claim saw.  Measured at 1080p x 1000 spp: as fast as single claims (366.9 vs 367.5 ms, the
+// same 2.3 ms of drain) with 30.1 instead of 43.0 MB of WRITE_SIZE; RTW_CLAIM_TAIL 8: 11 - 13 ms of drain; 24: +0.6 MB.
+// (Rejected: claims of 8 positions FAR APART in the frame -- no drain, but 1 % slower for the lost coherence, see above; a
+// static share of the queue per workgroup, no atomics at all -- the workgroups' shares differ by +-35 % in cost, 438 ms.)
 // Another die's queue is only ever visited at its end: single claims there.  Returns false when every queue is exhausted.
 #ifndef RTW_JOB_CLAIM
 #define RTW_JOB_CLAIM 8u
 #endif
 #ifndef RTW_CLAIM_TAIL
-#define RTW_CLAIM_TAIL 4u      // single claims once fewer than RTW_JOB_CLAIM x this many positions per workgroup of the die are left
+#define RTW_CLAIM_TAIL 16u
 #endif
-static_assert(RTW_JOB_CLAIM == 1u || RTW_JOB_CLAIM == 2u || RTW_JOB_CLAIM == 4u || RTW_JOB_CLAIM == 8u || RTW_JOB_CLAIM == 16u, "power of two");
-// queue position -> (tile within the queue, sub-block).  The queue's tiles are cut into RTW_JOB_CLAIM equal STREAMS (stream k =
-// tiles [k S, (k + 1) S), S = ceil(tiles / RTW_JOB_CLAIM)); position = (step << (CS + sub_shift)) | sub-block << CS | stream:
-// the RTW_JOB_CLAIM positions of one claim are the same sub-block of tile `step` of every stream -- far apart in the frame.
-// A bijection onto [0, S x RTW_JOB_CLAIM x subs); tiles beyond the queue's last (the padding of the last stream) do not exist
-// and are skipped like blocks outside the image.
-__device__ __forceinline__ unsigned queue_stream_len(const KParams &P, unsigned xq) { return (queue_tiles(P, xq) + RTW_JOB_CLAIM - 1u) / RTW_JOB_CLAIM; }
-__device__ __forceinline__ void job_of_position(unsigned pos, unsigned sub_shift, unsigned stream_len, unsigned &qt, unsigned &q) {
-    constexpr unsigned CS = RTW_JOB_CLAIM == 1u ? 0u : RTW_JOB_CLAIM == 2u ? 1u : RTW_JOB_CLAIM == 4u ? 2u : RTW_JOB_CLAIM == 8u ? 3u : 4u;
-    const unsigned step = pos >> (CS + sub_shift), c = pos & ((1u << (CS + sub_shift)) - 1u);
-    qt = (c & (RTW_JOB_CLAIM - 1u)) * stream_len + step;
-    q = c >> CS;
-}
-__device__ __forceinline__ unsigned queue_positions(const KParams &P, unsigned xq, unsigned sub_shift) {
-    return (queue_stream_len(P, xq) * RTW_JOB_CLAIM) << sub_shift;
-}
 __device__ __forceinline__ bool claim_job(const KParams &P, DevCounters *ctr, JobCache *C, unsigned xcd, unsigned sub_shift, unsigned &xq_out, unsigned &gq_out) {
     constexpr unsigned long long M28 = (1ull << 28) - 1ull;
     for (;;) {
@@ -270,10 +261,10 @@ __device__ __forceinline__ bool claim_job(const KParams &P, DevCounters *ctr, Jo
         while (off < 8u) {
             const unsigned xq = (xcd + off) & 7u;
             const unsigned q_pos = queue_positions(P, xq, sub_shift);
-            // several positions per claim only while plenty is left for everybody (what this workgroup's previous claim returned
-            // tells how far the queue is; the other workgroups of the die claim about as much in between)
+            // guided self-scheduling (what this workgroup's previous claim returned tells how far the queue is)
             const unsigned seen = C->last_g, left = q_pos > seen ? q_pos - seen : 0u;
-            const unsigned n = (locked && off == 0u && left > RTW_JOB_CLAIM * RTW_CLAIM_TAIL * (gridDim.x / 8u + 1u)) ? RTW_JOB_CLAIM : 1u;
+            unsigned n = 1u;
+            if (locked && off == 0u) { n = left / (RTW_CLAIM_TAIL * (gridDim.x / 8u + 1u)); n = n > RTW_JOB_CLAIM ? RTW_JOB_CLAIM : n < 1u ? 1u : n; }
             const unsigned g0 = atomicAdd(&ctr->next_job[xq], n);
             if (off == 0u) C->last_g = g0;
             if (g0 >= q_pos) { off += 1u; continue; }            // this queue is exhausted (for good): the next die's
@@ -301,9 +292,8 @@ __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned la
         if (lane == 0) ok = claim_job(P, ctr, jcache, xcd, sub_shift, xq, gq) ? 1u : 0u;
         if (!uniform(ok)) break;
         xq = uniform(xq); gq = uniform(gq);
-        unsigned qt, q, tj, ti;                                  // tile within the queue, block within the tile
-        job_of_position(gq, sub_shift, queue_stream_len(P, xq), qt, q);
-        if (qt >= queue_tiles(P, xq)) continue;                  // (padding of the queue's last stream)
+        const unsigned qt = gq >> sub_shift, q = gq & ((1u << sub_shift) - 1u);      // tile within the queue, block within the tile
+        unsigned tj, ti;
         if (P.shard_count == 1) {
             const unsigned tjq = udiv_magic(qt, P.div_tiles_m, P.div_tiles_s);
             ti = qt - tjq * (unsigned)P.tiles_i; tj = xq + 8u * tjq;

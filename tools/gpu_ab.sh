@@ -3,7 +3,7 @@
 #   usage: tools/gpu_ab.sh "<name>=<EXTRA compiler flags>" ...      env: BENCH_ARGS (extra bench.py flags), DRAIN=1 (drain profile instead)
 #   e.g.   tools/gpu_ab.sh "base=" "claim1=-DRTW_JOB_CLAIM=1u" "w6=-DRTW_TRACE_WAVES_MFMA_F32=6"
 # Build-time switches worth knowing: RTW_TRACE_WAVES_MFMA_F32/_F64 (occupancy), RTW_SCAN_GROUP (1|4), RTW_SCAN_SKIP (0|1),
-# RTW_JOB_CLAIM (1..16), RTW_CLAIM_TAIL; run-time: RTW_JOB_PIXELS (1|4|8|16), RTW_SCAN=valu.
+# RTW_JOB_CLAIM (1..16: most positions per claim), RTW_CLAIM_TAIL (guided-claim divisor); run-time: RTW_JOB_PIXELS (1|4|8|16), RTW_SCAN=valu.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
