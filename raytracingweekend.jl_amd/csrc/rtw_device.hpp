@@ -387,8 +387,14 @@ template <typename T> struct DevScene {
 __device__ __forceinline__ uint32_t sign_word(float x) { return __float_as_uint(x); }
 __device__ __forceinline__ uint32_t sign_word(double x) { return (uint32_t)((uint64_t)__double_as_longlong(x) >> 32); }
 
+// Spheres per scalar load of the all-VALU scan.  Two groups are in SGPRs at a time (one being tested, one in flight): 2 x 16
+// registers each.  Float32 used groups of 8 (2 x 32 SGPRs of the 102 a wave has) until round 3: every other long-lived scalar
+// of the kernel then competes for ~30 registers, and whether the allocator spilled them around the scan loop or INSIDE it (47
+// v_readlane / v_writelane per 16 spheres, +30 % kernel time) changed with unrelated edits to the kernel's epilogue.  With
+// groups of 4 the loop has no spill code at all and runs 10 % faster than the best groups-of-8 build (255 vs 286 ms at 1080p x
+// 300 spp); the 33 VALU instructions between a load and its use are plenty at 7 waves per SIMD.
 template <typename T> struct ScanGroup;
-template <> struct ScanGroup<float> { static constexpr int N = 8; };    // 8 x 16 B = 2 x s_load_dwordx16
+template <> struct ScanGroup<float> { static constexpr int N = 4; };    // 4 x 16 B = 1 x s_load_dwordx16
 template <> struct ScanGroup<double> { static constexpr int N = 4; };   // 4 x 8 floats = 2 x s_load_dwordx16
 
 struct NoClock { __device__ __forceinline__ void lap(int) {} __device__ __forceinline__ void count(int, unsigned) {} };

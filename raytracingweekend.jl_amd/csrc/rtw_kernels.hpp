@@ -85,7 +85,9 @@ template <typename T> struct WgShared {
     unsigned char slots[RTW_SLOT_BYTES];      // n_slots x (128-byte JobSlot + 64 bytes per job pixel)
     __device__ __forceinline__ JobSlot *slot(unsigned i, unsigned stride) { return reinterpret_cast<JobSlot *>(slots + i * stride); }
     unsigned ticket;                         // next batch of this workgroup
-    unsigned pad[3];
+    unsigned fin_waves;                      // waves of this workgroup that have finished, and what they counted: the last one adds
+    unsigned long long fin_segments, fin_samples;   // it to DevCounters (one pair of global atomics per workgroup, not per wave)
+    unsigned long long t_wave[8];            // wall clock at the start [0..3] and the end [4..7] of each wave (RTW_DRAIN_PROFILE)
     JobCache jobs;                           // queue positions claimed but not started yet (claim_job)
     Camera<T> cam;                           // read per new sample (keeps 22 SGPRs out of the scan loop)
     KParams P;                               // read where needed (item pull, store): not held in SGPRs across the scan
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
     }
     unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + (CULL ? cull_exact_count(cull) : 0));
     if (threadIdx.x < P_arg.n_slots) { JobSlot *S0 = sh->slot(threadIdx.x, P_arg.slot_stride); S0->ready_seq = RTW_SLOT_FREE; S0->job = 0u; }
-    if (threadIdx.x == 0) { sh->ticket = 0u; sh->jobs.jc = 0ull; sh->jobs.jc_lock = 0u; sh->jobs.queue_off = 0u; sh->jobs.last_g = 0u; sh->cam = cam_arg; sh->P = P_arg; }
+    if (threadIdx.x == 0) { sh->ticket = 0u; sh->fin_waves = 0u; sh->fin_segments = 0ull; sh->fin_samples = 0ull; sh->jobs.jc = 0ull; sh->jobs.jc_lock = 0u; sh->jobs.queue_off = 0u; sh->jobs.last_g = 0u; sh->cam = cam_arg; sh->P = P_arg; }
     const KParams &P = sh->P;
     if (LDS_SCENE) {
         if (CULL) stage_cull_scene<T>(cull, lds_geom, lds_orig);
@@ -360,12 +362,13 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
     }
     __syncthreads();
 
-    const unsigned long long t_wave_start = wall_clock64();
+    if (lane == 0) sh->t_wave[threadIdx.x >> 6] = wall_clock64();     // (in LDS: not a register pair held across the lane loop)
     // ---- wave-uniform state ----
     unsigned pool_next = 0, pool_end = 0;   // unassigned items [pool_next, pool_end) of the wave's current batch
     unsigned pool_slot = 0, pool_b = 0;
     bool have_ticket = false;               // a batch ticket drawn but not yet usable (its job slot is not open)
     unsigned tk_seq = 0, tk_b = 0;
+
     unsigned long long n_segments = 0, n_samples = 0;
 
     // ---- per-lane state that lives across iterations (and so across the scan) ----
@@ -378,7 +381,6 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
     Rng rng = {1, 2};
     V3<T> ro = {0, 0, 0}, rd = {0, 0, 1};
     double thr_r = 1, thr_g = 1, thr_b = 1;
-
     const T w_div = (T)(float)P.width;    // f32_image_width  (src/render.jl:16)
     const T h_div = (T)(float)P.height;   // f32_image_height (src/render.jl:17)
 
@@ -639,16 +641,31 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         for (int k = 0; k < 8; ++k) atomicAdd(&ctr->phase[k], clk.acc[k]);
     }
     if (lane == 0) {
-        atomicAdd(&ctr->segments, n_segments);
-        atomicAdd(&ctr->samples, n_samples);
-        const unsigned long long t_wave_end = wall_clock64();
-        atomicMin(&ctr->t_first, t_wave_start);
-        atomicMax(&ctr->t_last, t_wave_end);
-        atomicAdd(&ctr->t_end_sum, t_wave_end);
-        atomicAdd(&ctr->n_waves, 1ull);
-        const unsigned long long t0 = __hip_atomic_load(&ctr->t_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long bin = (t_wave_end - t0) / 25000ull;
-        atomicAdd(&ctr->end_hist[bin < 4095ull ? (unsigned)bin : 4095u], 1u);
+        // A global atomic is a 32-byte write at the memory side: the waves of a workgroup add up in LDS and the last one to
+        // finish reports for all four.
+        __hip_atomic_fetch_add(&sh->fin_segments, n_segments, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sh->fin_samples, n_samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&sh->t_wave[4u + (threadIdx.x >> 6)], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__hip_atomic_fetch_add(&sh->fin_waves, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 3u) {      // (256 threads: four waves)
+            atomicAdd(&ctr->segments, __hip_atomic_load(&sh->fin_segments, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            atomicAdd(&ctr->samples, __hip_atomic_load(&sh->fin_samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            // the end-of-queue drain: first wave start, last wave end, sum of the wave ends, waves by end time
+            unsigned long long t_start = ~0ull, t_end = 0ull, t_sum = 0ull;
+            for (unsigned w = 0; w < 4u; ++w) {
+                const unsigned long long a = __hip_atomic_load(&sh->t_wave[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long e = __hip_atomic_load(&sh->t_wave[4u + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                t_start = a < t_start ? a : t_start; t_end = e > t_end ? e : t_end; t_sum += e;
+            }
+            const unsigned long long t0_seen = atomicMin(&ctr->t_first, t_start);
+            atomicMax(&ctr->t_last, t_end);
+            atomicAdd(&ctr->t_end_sum, t_sum);
+            atomicAdd(&ctr->n_waves, 4ull);
+            const unsigned long long t0 = t0_seen < t_start ? t0_seen : t_start;
+            for (unsigned w = 0; w < 4u; ++w) {
+                const unsigned long long bin = (__hip_atomic_load(&sh->t_wave[4u + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - t0) / 25000ull;
+                atomicAdd(&ctr->end_hist[bin < 4095ull ? (unsigned)bin : 4095u], 1u);
+            }
+        }
     }
 }
 
