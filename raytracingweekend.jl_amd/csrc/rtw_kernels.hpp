@@ -264,11 +264,11 @@ __device__ __forceinline__ bool claim_job(const KParams &P, DevCounters *ctr, Jo
             const unsigned xq = (xcd + off) & 7u;
             const unsigned q_pos = queue_positions(P, xq, sub_shift);
             // guided self-scheduling (what this workgroup's previous claim returned tells how far the queue is)
-            const unsigned seen = C->last_g, left = q_pos > seen ? q_pos - seen : 0u;
+            const unsigned seen = __hip_atomic_load(&C->last_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), left = q_pos > seen ? q_pos - seen : 0u;
             unsigned n = 1u;
             if (locked && off == 0u) { n = left / (RTW_CLAIM_TAIL * (gridDim.x / 8u + 1u)); n = n > RTW_JOB_CLAIM ? RTW_JOB_CLAIM : n < 1u ? 1u : n; }
             const unsigned g0 = atomicAdd(&ctr->next_job[xq], n);
-            if (off == 0u) C->last_g = g0;
+            if (off == 0u) __hip_atomic_store(&C->last_g, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (any wave's: a recent position)
             if (g0 >= q_pos) { off += 1u; continue; }            // this queue is exhausted (for good): the next die's
             xq_out = xq; gq_out = g0; got = true;
             const unsigned end = g0 + n < q_pos ? g0 + n : q_pos;
