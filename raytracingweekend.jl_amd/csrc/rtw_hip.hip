@@ -680,7 +680,9 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     const long long total_jobs = n_local * (64 >> job_shift);
     const long long cpb = 64 >> job_shift;
     const long long bpj = (nch + cpb - 1) / cpb;
-    if (total_jobs >= (1ll << 31) || total_jobs * bpj >= (1ll << 40))
+    // (claim_job packs a queue position into 28 bits; queue 0 is the longest: every 8th tile column, or every 8th tile of a shard)
+    const long long queue0_jobs = (p->shard_count == 1 ? (long long)((K.tiles_j + 7) / 8) * K.tiles_i : (n_local + 7) / 8) * (64 >> job_shift);
+    if (total_jobs >= (1ll << 31) || queue0_jobs >= (1ll << 28) || total_jobs * bpj >= (1ll << 40))
         return fail(-5, "render too large for one call: %lld pixel-block jobs", total_jobs);
     K.total_jobs = (unsigned)total_jobs; K.local_tiles = (unsigned)n_local; K.bpj = (unsigned)bpj; K.job_shift = (unsigned)job_shift;
     K.rows_shift = (unsigned)std::min(job_shift, 3);       // 4 x 1, 8 x 1, 8 x 2 pixels: whole column strips

@@ -312,3 +312,47 @@ def test_host_entry_point_reuses_its_context(rtw):
     _capi.check(L.rtw_render_f32(C.byref(S), C.byref(Cm), C.byref(P), out2.ctypes.data_as(C.c_void_p)))
     assert np.array_equal(out2, ref)
     del keep, keep2
+
+
+# ---- job queues: frames that fill the eight queues very unevenly, and the size limit ------------------------------------
+@pytest.mark.parametrize("W,H", [(8, 2048), (24, 1000), (2048, 8), (72, 9)])
+def test_narrow_and_flat_frames(oracle, rtw, W, H):
+    """Tile column tj belongs to job queue tj mod 8 (claim_job): an 8-pixel-wide frame has ONE non-empty queue, a 24-pixel-wide one
+    three -- every workgroup then takes its jobs from another die's queue.  The C ABI takes the height from the caller, so frames
+    need not be 16:9.  Bit-exact against the oracle, every pixel sample counted once."""
+    from test_gpu_render import gpu_render
+    T = np.float32
+    rtw.reseed()
+    scene = rtw.scene_random_spheres(elem_type=T)
+    cam = rtw.t_cam1(elem_type=T)
+    g = dict(flat=rtw.flatten_scene(scene, T), cam=_cam_dict(cam, oracle), image=np.zeros(1, T), width=W, height=H, spp=8, depth=16,
+             seed=5, n_chunks=2)
+    img, st = gpu_render(g)
+    ref, ost = oracle.render(g["flat"], g["cam"], W, H, 8, T=T, max_depth=16, seed=5, n_chunks=2)
+    assert np.array_equal(img, ref)
+    assert st.samples == W * H * 8 and st.segments == ost["segments"]
+
+
+def test_render_too_large_is_an_error(rtw):
+    """claim_job packs a queue position into 28 bits: a frame whose longest queue would hold 2^28 jobs is refused (-5) before
+    anything is launched or written (the output pointer is never touched)."""
+    import ctypes as C
+    import torch
+    from rtw_amd import _capi
+    T = np.float32
+    rd = rtw.DeviceRenderer(rtw.scene_2_spheres(elem_type=T), rtw.default_camera(elem_type=T), device=0)
+    dummy = torch.zeros(16, dtype=torch.float32, device="cuda:0")
+    L = _capi.lib()
+    for w, h, ok in ((8, 1 << 27, False), (1 << 17, 1 << 17, False), (64, 36, True)):
+        P = _capi.make_params(w, h, 1, 4, 1, 0, 0, 1, -1, 1, 0)
+        P.job_pixels = 4
+        out = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda:0") if ok else dummy
+        rc = L.rtw_render_device_f32(rd.handle, C.byref(rd.cam), C.byref(P), C.c_void_p(out.data_ptr()), C.c_void_p(0))
+        if ok:
+            assert rc == 0
+            assert rd.stats()["samples"] == w * h
+        else:
+            assert rc == -5 and b"too large" in L.rtw_last_error(), (w, h, rc, L.rtw_last_error())
+    torch.cuda.synchronize()
+    assert float(dummy.abs().sum()) == 0.0
+    rd.close()
