@@ -393,6 +393,9 @@ __device__ __forceinline__ uint32_t sign_word(double x) { return (uint32_t)((uin
 // v_readlane / v_writelane per 16 spheres, +30 % kernel time) changed with unrelated edits to the kernel's epilogue.  With
 // groups of 4 the loop has no spill code at all and runs 10 % faster than the best groups-of-8 build (255 vs 286 ms at 1080p x
 // 300 spp); the 33 VALU instructions between a load and its use are plenty at 7 waves per SIMD.
+#ifndef RTW_SCAN_PRIO
+#define RTW_SCAN_PRIO 1   // wave priorities of the Float32 matrix-pipe kernels (hit_world_mfma); 0: no s_setprio at all (A/B)
+#endif
 template <typename T> struct ScanGroup;
 template <> struct ScanGroup<float> { static constexpr int N = 4; };    // 4 x 16 B = 1 x s_load_dwordx16
 template <> struct ScanGroup<double> { static constexpr int N = 4; };   // 4 x 8 floats = 2 x s_load_dwordx16
@@ -809,6 +812,12 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         cmargin = margin;                                 // (o +- margin is formed per block: 6 more VALU, 5 fewer live registers)
     }
     uint4 A1 = pa[0], A2 = pa[64];
+    // Wave priority: low inside the block loop, raised for everything else (pass 2 and the divergent phases of the lane loop are
+    // chains of dependent LDS / VALU instructions; a wave in the block loop issues a 32-cycle MFMA pair and waits for it
+    // anyway).  Measured at Float32: 372.1 -> 368.0 ms on one box, 361.8 -> 359.9 on a faster one, group cull 345.6 -> 343.0; which of
+    // the levels 1 - 3 made no difference.  Float64 (4 waves per SIMD) lost 0.35 % with it (1152.7 -> 1156.8 ms): Float32 only.
+    constexpr bool use_prio = RTW_SCAN_PRIO != 0 && sizeof(T) == 4;
+    if (use_prio) __builtin_amdgcn_s_setprio(0);
     for (int blk = 0; blk < n_blocks; ++blk) {
         if constexpr (CULLED) {
             const float lx = gbox[8 * blk], ly = gbox[8 * blk + 1], lz = gbox[8 * blk + 2];
@@ -940,6 +949,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         }
         clk.lap(4);
     }
+    if (use_prio) __builtin_amdgcn_s_setprio(1);
     resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);
 #ifdef RTW_DUP_RESOLVE_PAIRS   // instruction/time probe: the final resolve twice (idempotent: min / max of the same keys)
     resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);

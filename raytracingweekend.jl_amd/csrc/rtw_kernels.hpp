@@ -613,10 +613,15 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
               while (__any(p2)) { if (p2) { l2 = reject_trial<T>(r2, ball, q2); p2 = !(l2 <= T(1)); } }
               __asm__ volatile("" :: "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(l2), "v"((unsigned)r2.x), "v"((unsigned)r2.y)); }
 #endif
+            // (wave priority, Float32 matrix-pipe kernels -- see hit_world_mfma: this loop is pure VALU work, a filler like the block
+            //  loop; 364.0 -> 363.0 ms)
+            constexpr bool use_prio = MFMA && sizeof(T) == 4 && RTW_SCAN_PRIO != 0;
+            if (use_prio) __builtin_amdgcn_s_setprio(0);
             while (pending) {
                 len2 = reject_trial<T>(rng, ball, rp);
                 pending = !(len2 <= T(1));
             }
+            if (use_prio) __builtin_amdgcn_s_setprio(1);
         }
         // ---- (F) finish the scatter / the camera ray; ONE normalize for all of them ----
         if (ball) {
