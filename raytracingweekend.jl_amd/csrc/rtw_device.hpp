@@ -815,9 +815,11 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     // Wave priority: low inside the block loop, raised for everything else (pass 2 and the divergent phases of the lane loop are
     // chains of dependent LDS / VALU instructions; a wave in the block loop issues a 32-cycle MFMA pair and waits for it
     // anyway).  Measured at Float32: 372.1 -> 368.0 ms on one box, 361.8 -> 359.9 on a faster one, group cull 345.6 -> 343.0; which of
-    // the levels 1 - 3 made no difference.  Float64 (4 waves per SIMD) lost 0.35 % with it (1152.7 -> 1156.8 ms): Float32 only.
-    constexpr bool use_prio = RTW_SCAN_PRIO != 0 && sizeof(T) == 4;
-    if (use_prio) __builtin_amdgcn_s_setprio(0);
+    // the levels 1 - 3 made no difference.  Float64 (4 waves per SIMD, FP64 instructions of two issue slots in pass 2 and the
+    // shading) is the other way round: 1152.7 -> 1156.8 ms with these levels, 1144.7 -> 1134.6 with the block loop HIGH and the
+    // rest low -- so that is what it gets.
+    constexpr bool use_prio = RTW_SCAN_PRIO != 0;
+    if (use_prio) __builtin_amdgcn_s_setprio(sizeof(T) == 4 ? 0 : 1);
     for (int blk = 0; blk < n_blocks; ++blk) {
         if constexpr (CULLED) {
             const float lx = gbox[8 * blk], ly = gbox[8 * blk + 1], lz = gbox[8 * blk + 2];
@@ -949,7 +951,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         }
         clk.lap(4);
     }
-    if (use_prio) __builtin_amdgcn_s_setprio(1);
+    if (use_prio) __builtin_amdgcn_s_setprio(sizeof(T) == 4 ? 1 : 0);
     resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);
 #ifdef RTW_DUP_RESOLVE_PAIRS   // instruction/time probe: the final resolve twice (idempotent: min / max of the same keys)
     resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);
