@@ -70,7 +70,7 @@ typedef struct {
 #define RTW_FLAG_COMPACT_TILES 2
 /* RTW_FLAG_SCAN_VALU: run the plain scan entirely on the vector ALUs (the contract discriminant for every
  * sphere and every ray, 11 instructions each).  Default (0): pass 1 of the plain scan is a conservative filter
- * on the matrix pipe (v_mfma_f32_32x32x16_f16 over f16-split features), ~1.9x faster; the
+ * on the matrix pipe (v_mfma_f32_32x32x16_f16 over f16-split features), ~2.3x faster; the
  * exact contract test still decides every hit, so the image is the same bit for bit.  For A/B measurements
  * and as the reference the filter is tested against; also what the library uses by itself for scenes whose
  * extent the f16 split cannot cover (|coordinates| or radii beyond 2^40 or all below 2^-40). */
