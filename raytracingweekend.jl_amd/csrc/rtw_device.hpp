@@ -638,6 +638,7 @@ struct WaveScratch {
     unsigned *pairs;              // RTW_PAIR_CAP entries: recording lane << 16 | block << 5 | bit (see resolve_pairs)
     unsigned long long *keys;     // 64 entries: Float32 (root bits << 32 | ~sphere); Float64 root bits
     unsigned *kidx;               // Float64 only: 64 entries, sphere + 1
+    unsigned cap = RTW_PAIR_CAP;  // entries in `pairs` (wave-uniform; the ray-pool kernel gives a wave 256)
 };
 
 // x = p1 + p2 with p1 = RN16(x), p2 = RN16(x - p1); returns p1 | p2 << 16
@@ -935,7 +936,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         for (;;) {
             const unsigned long long act = __ballot(m != 0u);
             if (!act) break;
-            if (total + 64u > RTW_PAIR_CAP) {
+            if (total + 64u > ws.cap) {
                 clk.lap(4);
                 resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);
                 total = 0;

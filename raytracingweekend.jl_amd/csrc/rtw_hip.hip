@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "rtw_kernels.hpp"
+#include "rtw_pool.hpp"
 #include "rtw_units.hpp"
 
 namespace {
@@ -72,7 +73,7 @@ struct RenderRec {
     bool used = false;                   // ev1 has been recorded at least once
     bool done = true;                    // the kernel recorded by ev1 is known to have finished (no hipEventQuery needed)
     bool owned = false;                  // referenced by some thread's "last render"
-    int n_spheres = 0, n_chunks = 0, grid = 0;
+    int n_spheres = 0, n_chunks = 0, grid = 0, block = 256;
     ~RenderRec() {
         if (ctr) HIP_IGNORE(hipFree(ctr));
         if (ev0) HIP_IGNORE(hipEventDestroy(ev0));
@@ -581,7 +582,7 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
-    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU)) return fail(-2, "unknown flags 0x%x", p->flags);
+    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_LANE_LOOP)) return fail(-2, "unknown flags 0x%x", p->flags);
     // default rule: about 4 samples per chunk, between 16 and 256 chunks (never more than spp):
     // enough items for load balance, few enough stream set-ups (1 sample per chunk costs 7 % at Float64)
     int nch = p->n_chunks > 0 ? p->n_chunks : std::min(p->spp, std::max(16, std::min(256, p->spp / 4)));
@@ -657,8 +658,27 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     else if (mfma) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false, true> : (kern_t)rtw::trace_kernel<T, false, false, false, true>;
     else if (phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, false> : (kern_t)rtw::trace_kernel<T, true, false, false>;
     else kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false> : (kern_t)rtw::trace_kernel<T, false, false, false>;
+    // The ray-pool kernel (rtw_pool.hpp): Float32 plain scans on the matrix pipe, when the pool, the rings and the scene copy fit the
+    // 160 KB of LDS of a CU (one workgroup of RTW_POOL_W waves per CU).  RTW_FLAG_LANE_LOOP / RTW_POOL=0: the lane-loop kernel above.
+    static const bool env_no_pool = getenv("RTW_POOL") != nullptr && atoi(getenv("RTW_POOL")) == 0;
+    size_t pool_lds = 0;
+    bool pool = false;
+    typedef void (*pool_kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, T *, rtw::DevCounters *);
+    pool_kern_t pool_kern = nullptr;
+    if constexpr (sizeof(T) == 4) {
+        pool_lds = rtw::pool_fixed_lds_bytes<T, RTW_POOL_W, RTW_POOL_R>() + rtw::pool_scene_lds_bytes<T>(scene->n, scene->n_pad);
+        pool = mfma && !cull && !phase_profile && !env_no_pool && !(p->flags & RTW_FLAG_LANE_LOOP) && pool_lds <= 160u * 1024u &&
+               cs <= RTW_POOL_MAX_CHUNK_SPP;
+        pool_kern = (pool_kern_t)rtw::trace_pool_kernel<T, RTW_POOL_W, RTW_POOL_R, false>;
+    }
+    const int block_threads = pool ? RTW_POOL_W * 64 : 256;
     int blocks_per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 256, lds_bytes));
+    if (pool) {
+        HIP_TRY(hipFuncSetAttribute((const void *)pool_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, pool_kern, block_threads, pool_lds));
+    } else {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 256, lds_bytes));
+    }
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     long long grid = (long long)ctx->num_cus * blocks_per_cu;
     // Job size.  A job is owned by one workgroup, so its size sets the end-of-queue drain; smaller jobs also store the
@@ -692,14 +712,15 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     K.n_slots = std::min(24u, (unsigned)RTW_SLOT_BYTES / K.slot_stride);             // 24 / 12 / 7 / 4 slots of 1 / 4 / 8 / 16 pixels
     make_udiv(K.n_slots, &K.div_slots_m, &K.div_slots_s);
     make_udiv((unsigned)bpj, &K.div_bpj_m, &K.div_bpj_s);
-    const long long max_useful = (total_jobs * bpj + 3) / 4;          // one batch per wave, 4 waves per block
+    const long long max_useful = pool ? (total_jobs * bpj * 64 + RTW_POOL_R - 1) / RTW_POOL_R       // one item per slot of the pool
+                                      : (total_jobs * bpj + 3) / 4;                                // one batch per wave, 4 waves per block
     if (grid > max_useful) grid = max_useful;
     if (grid < 1) grid = 1;
 
     RenderRec *rec;
     if (int rc = acquire_rec(ctx.get(), &rec)) return rc;
     *rec_out = rec;
-    rec->n_spheres = scene->n; rec->n_chunks = nch; rec->grid = (int)grid;
+    rec->n_spheres = scene->n; rec->n_chunks = nch; rec->grid = (int)grid; rec->block = block_threads;
     HIP_TRY(hipMemsetAsync(rec->ctr, 0, sizeof(rtw::DevCounters), stream));
     HIP_TRY(hipMemsetAsync(&rec->ctr->t_first, 0xff, sizeof(unsigned long long), stream));
     // pixels of other shards read 0 in the full-frame layout (the sum over the shards is the image)
@@ -708,7 +729,8 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     HIP_TRY(hipEventRecord(rec->ev0, stream));
     if (total_jobs > 0) {
         (void)hipGetLastError();           // (hipEventQuery's hipErrorNotReady in acquire_rec must not be mistaken for a launch failure)
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, CS, (T *)d_out, rec->ctr);
+        if (pool) hipLaunchKernelGGL(pool_kern, dim3((unsigned)grid), dim3((unsigned)block_threads), pool_lds, stream, K, C, S, (T *)d_out, rec->ctr);
+        else hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, CS, (T *)d_out, rec->ctr);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(rec->ev1, stream));
@@ -735,6 +757,11 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
             fprintf(stderr, "[rtw phase profile] matrix-pipe scan: %.1f%% of the (wave, block of 32 spheres) evaluations found no candidate in any lane (%llu of %llu)\n",
                     100.0 * (double)c.phase[6] / (double)c.phase[7], (unsigned long long)c.phase[6], (unsigned long long)c.phase[7]);
     }
+    if (c.end_hist[0] == 0xdeadbeefu) {        // (RTW_POOL_WATCHDOG builds: the pool kernel gave up; its state)
+        fprintf(stderr, "[rtw pool watchdog]");
+        for (int k = 1; k <= 113; ++k) fprintf(stderr, " %u", c.end_hist[k]);
+        fprintf(stderr, "\n");
+    }
     if (getenv("RTW_DRAIN_PROFILE") && c.n_waves) {
         const double span = (double)(c.t_last - c.t_first) * 1e-5, mean_end = ((double)c.t_end_sum / (double)c.n_waves - (double)c.t_first) * 1e-5;
         fprintf(stderr, "[rtw drain profile] %llu waves: kernel span %.2f ms, mean wave end at %.2f ms -> %.2f ms (%.1f %%) of idle wave slots at the end of the queue\n",
@@ -752,7 +779,7 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
     agg->total_ms = std::max(agg->total_ms, (double)k_ms);
     agg->n_chunks = r->n_chunks;
     agg->grid_blocks = std::max(agg->grid_blocks, r->grid);
-    agg->block_threads = 256;
+    agg->block_threads = std::max(agg->block_threads, r->block);
     return 0;
 }
 
