@@ -75,11 +75,12 @@ typedef struct {
  * and as the reference the filter is tested against; also what the library uses by itself for scenes whose
  * extent the f16 split cannot cover (|coordinates| or radii beyond 2^40 or all below 2^-40). */
 #define RTW_FLAG_SCAN_VALU 4
-/* RTW_FLAG_LANE_LOOP: trace with the round-1..3 kernel, in which every lane keeps its own ray from the camera to the sky
- * (rtw_kernels.hpp).  Default (0): Float32 plain scans on the matrix pipe use the ray-pool kernel (rtw_pool.hpp: the rays of a
- * workgroup are parked in LDS between the stages scan / shade / path end, and every stage runs on full waves of one kind).
- * Scheduling only -- the image is identical bit for bit; kept for A/B measurements and as the cross-check of the pool kernel. */
-#define RTW_FLAG_LANE_LOOP 8
+/* RTW_FLAG_RAY_POOL (Float32 plain scans on the matrix pipe; ignored otherwise): trace with the ray-pool kernel (rtw_pool.hpp) -- the
+ * rays of a workgroup are parked in LDS between the stages scan / shade / path end and every stage runs on full waves of one
+ * kind, instead of every lane keeping its own ray from the camera to the sky (rtw_kernels.hpp, the default).  Scheduling only:
+ * the image is identical bit for bit.  Measured 14 % SLOWER than the default on MI355X (DESIGN.md section 6.4 says why); kept as
+ * an independent cross-check of the default kernel and as the starting point for hardware with more LDS per CU. */
+#define RTW_FLAG_RAY_POOL 8
 
 /* Positional arguments of render() plus the keyword extras of the shim. */
 typedef struct {

@@ -120,7 +120,7 @@ def make_camera(cam, T):
 FLAG_GROUP_CULL = 1      # include/rtw_hip.h RTW_FLAG_GROUP_CULL
 FLAG_COMPACT_TILES = 2   # include/rtw_hip.h RTW_FLAG_COMPACT_TILES
 FLAG_SCAN_VALU = 4       # include/rtw_hip.h RTW_FLAG_SCAN_VALU
-FLAG_LANE_LOOP = 8       # include/rtw_hip.h RTW_FLAG_LANE_LOOP
+FLAG_RAY_POOL = 8        # include/rtw_hip.h RTW_FLAG_RAY_POOL
 ABI_VERSION = 2
 
 

@@ -582,7 +582,7 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
-    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_LANE_LOOP)) return fail(-2, "unknown flags 0x%x", p->flags);
+    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_RAY_POOL)) return fail(-2, "unknown flags 0x%x", p->flags);
     // default rule: about 4 samples per chunk, between 16 and 256 chunks (never more than spp):
     // enough items for load balance, few enough stream set-ups (1 sample per chunk costs 7 % at Float64)
     int nch = p->n_chunks > 0 ? p->n_chunks : std::min(p->spp, std::max(16, std::min(256, p->spp / 4)));
@@ -658,18 +658,19 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     else if (mfma) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false, true> : (kern_t)rtw::trace_kernel<T, false, false, false, true>;
     else if (phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, false> : (kern_t)rtw::trace_kernel<T, true, false, false>;
     else kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false> : (kern_t)rtw::trace_kernel<T, false, false, false>;
-    // The ray-pool kernel (rtw_pool.hpp): Float32 plain scans on the matrix pipe, when the pool, the rings and the scene copy fit the
-    // 160 KB of LDS of a CU (one workgroup of RTW_POOL_W waves per CU).  RTW_FLAG_LANE_LOOP / RTW_POOL=0: the lane-loop kernel above.
-    static const bool env_no_pool = getenv("RTW_POOL") != nullptr && atoi(getenv("RTW_POOL")) == 0;
+    // The ray-pool kernel (rtw_pool.hpp; opt-in: RTW_FLAG_RAY_POOL, or RTW_POOL=1 in the environment for A/B runs): Float32 plain
+    // scans on the matrix pipe, when the pool, the rings and the scene copy fit the 160 KB of LDS of a CU (one workgroup of
+    // RTW_POOL_W waves per CU); everything else runs the lane-loop kernel above.
+    static const bool env_pool = getenv("RTW_POOL") != nullptr && atoi(getenv("RTW_POOL")) != 0;
     size_t pool_lds = 0;
     bool pool = false;
     typedef void (*pool_kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, T *, rtw::DevCounters *);
     pool_kern_t pool_kern = nullptr;
     if constexpr (sizeof(T) == 4) {
         pool_lds = rtw::pool_fixed_lds_bytes<T, RTW_POOL_W, RTW_POOL_R>() + rtw::pool_scene_lds_bytes<T>(scene->n, scene->n_pad);
-        pool = mfma && !cull && !phase_profile && !env_no_pool && !(p->flags & RTW_FLAG_LANE_LOOP) && pool_lds <= 160u * 1024u &&
+        pool = mfma && !cull && (env_pool || (p->flags & RTW_FLAG_RAY_POOL)) && pool_lds <= 160u * 1024u &&
                cs <= RTW_POOL_MAX_CHUNK_SPP;
-        pool_kern = (pool_kern_t)rtw::trace_pool_kernel<T, RTW_POOL_W, RTW_POOL_R, false>;
+        pool_kern = phase_profile ? (pool_kern_t)rtw::trace_pool_kernel<T, RTW_POOL_W, RTW_POOL_R, true> : (pool_kern_t)rtw::trace_pool_kernel<T, RTW_POOL_W, RTW_POOL_R, false>;
     }
     const int block_threads = pool ? RTW_POOL_W * 64 : 256;
     int blocks_per_cu = 0;
@@ -747,7 +748,16 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
     HIP_TRY(hipEventElapsedTime(&k_ms, r->ev0, r->ev1));
     rtw::DevCounters c;                    // (16 KB incl. the drain histogram)
     HIP_TRY(hipMemcpy(&c, r->ctr, sizeof c, hipMemcpyDeviceToHost));
-    if (getenv("RTW_PHASE_PROFILE")) {
+    if (getenv("RTW_PHASE_PROFILE") && r->block != 256) {
+        const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(c.end_hist + 256);
+        static const char *names[6] = {"SCAN", "LM", "END", "DIEL", "REJ", "WAIT"};
+        const double tot = (double)pp[26];
+        fprintf(stderr, "[rtw pool profile] wave-cycles %.4g; idle %.1f%%; lost pops %llu; blocks without a candidate %.1f%% of %llu\n", tot, 100.0 * (double)pp[24] / tot, (unsigned long long)pp[25],
+                pp[28] ? 100.0 * (double)pp[27] / (double)pp[28] : 0.0, (unsigned long long)pp[28]);
+        for (int k = 0; k < 6; ++k)
+            fprintf(stderr, "[rtw pool profile]   %-5s batches %10llu  mean fill %5.1f  %5.1f%% of wave-cycles  %7.0f cycles/batch\n", names[k], (unsigned long long)pp[4 * k],
+                    pp[4 * k] ? (double)pp[4 * k + 1] / (double)pp[4 * k] : 0.0, 100.0 * (double)pp[4 * k + 2] / tot, pp[4 * k] ? (double)pp[4 * k + 2] / (double)pp[4 * k] : 0.0);
+    } else if (getenv("RTW_PHASE_PROFILE")) {
         double tot = 0;
         for (int k = 0; k < 6; ++k) tot += (double)c.phase[k];
         fprintf(stderr, "[rtw phase profile] wave-cycles: pull %.1f%%  sample+scatter finish %.1f%%  scan-pass1/level1 %.1f%%  extract/level2 %.1f%%  resolve %.1f%%  shade %.1f%%  (total %.3g)\n",

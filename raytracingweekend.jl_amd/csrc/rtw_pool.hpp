@@ -26,14 +26,15 @@
 namespace rtw {
 
 enum { PQ_SCAN = 0, PQ_LM = 1, PQ_END = 2, PQ_DIEL = 3, PQ_REJ = 4, PQ_WAIT = 5, PQ_COUNT = 6 };
+enum { PC_DEAD = 12, PC_BUSY = 13, PC_FREE = 14, PC_EOF = 15 };
 #define RTW_POOL_RING 2048u          // entries per queue ring (u16: slot | generation << 11); any queue can hold every slot
 #define RTW_POOL_RING_SHIFT 11
 #define RTW_POOL_PAIR_CAP 256u       // candidate list entries per wave (trace_kernel: 512)
 #ifndef RTW_POOL_LM_ROUNDS
-#define RTW_POOL_LM_ROUNDS 2         // unit-ball trials run inline by the Lambertian/Metal stage (100 %, 48 % utilisation)
+#define RTW_POOL_LM_ROUNDS 3         // unit-ball trials run inline by the Lambertian/Metal stage (100 %, 48 %, 23 % utilisation; 2: +2.5 %, 6: +1 %, 12: +5 % time)
 #endif
 #ifndef RTW_POOL_REJ_ROUNDS
-#define RTW_POOL_REJ_ROUNDS 2        // trials per visit of the straggler stage
+#define RTW_POOL_REJ_ROUNDS 3        // trials per visit of the straggler stage
 #endif
 // the `misc` word of a slot
 #define RTW_PM_SAMPLES 0x0fffffffu   // samples of the item still to start
@@ -46,6 +47,15 @@ enum { PQ_SCAN = 0, PQ_LM = 1, PQ_END = 2, PQ_DIEL = 3, PQ_REJ = 4, PQ_WAIT = 5,
 #endif
 #ifndef RTW_POOL_R
 #define RTW_POOL_R 1216              // slots per workgroup: 1024 in the waves' hands + 192 parked
+#endif
+#ifndef RTW_POOL_THR_PACK                     // ready thresholds, one byte per queue: SCAN | LM << 8 | END << 16 | DIEL << 24 | REJ << 32
+#define RTW_POOL_THR_PACK (64ull | 64ull << 8 | 48ull << 16 | 16ull << 24 | 32ull << 32 | 1ull << 40)
+#endif
+#ifndef RTW_POOL_POLL
+#define RTW_POOL_POLL 4                       // s_sleep argument of a wave that waits for a queue to become ready (x 64 cycles)
+#endif
+#ifndef RTW_POOL_MIN_BUSY
+#define RTW_POOL_MIN_BUSY (RTW_POOL_W / 4)    // a partial batch is taken only while fewer waves than this hold one
 #endif
 
 // Slot records.  Float32 (80 B): [0] o.xyz t  [16] d.xyz w  [32] rng  [48] thr_r thr_g  [64] thr_b ref_depth misc
@@ -72,21 +82,27 @@ template <> struct PoolRec<double> {
     static __device__ __forceinline__ int i_of(double w) { return (int)__double_as_longlong(w); }
 };
 
-// The item dispenser: trace_kernel's per-wave batch (ticket -> job slot -> 64 items) as ONE structure of the workgroup, used under
+// The item dispenser: trace_kernel's per-wave batch (job slot -> 64 items at a time) as ONE structure of the workgroup, used under
 // `lock` by the wave whose END batch needs items (a wave that held a private batch could starve the job it belongs to: it hands
-// items out only when it happens to run the END stage).
+// items out only when it happens to run the END stage).  There are no tickets: one job is dispensed at a time, batch after batch,
+// and the next job opens in ANY free job slot -- with trace_kernel's slot = sequence mod n_slots one slow job (a 50-bounce path
+// inside the glass sphere) blocks the dispenser as soon as the sequence wraps, and 1216 slots go through 12 jobs quickly.
 struct PoolDisp {
-    unsigned lock, ticket, next, end, slot, b, have_ticket, tk_seq, tk_b, pad;
+    unsigned lock, next, end, slot, b, have_job;
     unsigned long long valid;            // which of the batch's 64 items are real (chunk < n_chunks, pixel inside the image)
 };
 template <typename T, int W> struct PoolShared {
     unsigned char slots[RTW_SLOT_BYTES];                 // job slots, as in WgShared
     __device__ __forceinline__ JobSlot *slot(unsigned i, unsigned stride) { return reinterpret_cast<JobSlot *>(slots + i * stride); }
-    uint2 q[8];                                          // (head, tail) of each queue: free-running positions
-    unsigned dead;                                       // slots that found the job queues exhausted: the kernel ends at R
+    unsigned ctl[16];                                    // what a wave looks at to choose its next batch, ONE 64-byte read:
+                                                         //   [2q], [2q + 1] head and tail of queue q (free-running positions)
+                                                         //   [12] dead: slots that found the job queues exhausted -- the kernel ends at R
+                                                         //   [13] busy: waves that hold a batch right now
+                                                         //   [14] free job slots   [15] eof: the job queues are exhausted
     unsigned fin_waves;
     unsigned long long fin_segments, fin_samples;
     PoolDisp disp;
+    unsigned long long prof[32];                         // PROFILE instantiation: per stage (batches, slots, wave-cycles); [24] idle, [25] lost pops, [26] wave-cycles
     JobCache jobs;
     Camera<T> cam;
     KParams P;
@@ -99,6 +115,25 @@ template <typename T, int W, int R> __host__ __device__ constexpr size_t pool_fi
 template <typename T> __host__ __device__ inline size_t pool_scene_lds_bytes(int n, int n_pad) {
     const size_t n_alloc = (size_t)scene_geom_alloc(n, n_pad);
     return n_alloc * sizeof(typename Vec4<T>::type) + (n_alloc + 15) / 16 * 16;
+}
+
+// fx_accumulate with the three channels in flight together (the END stage adds 64 samples at a time: three dependent
+// LDS round trips per batch instead of six)
+__device__ __forceinline__ void fx_accumulate3(unsigned long long *a, double r, double g, double b) {
+    unsigned long long lo[3], hi[3], old[3] = {0ull, 0ull, 0ull};
+    bool ok[3];
+    ok[0] = fx_from_double(r, lo[0], hi[0]); ok[1] = fx_from_double(g, lo[1], hi[1]); ok[2] = fx_from_double(b, lo[2], hi[2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) if (ok[c]) old[c] = __hip_atomic_fetch_add(&a[2 * c], lo[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (ok[c]) {
+            const unsigned long long h = hi[c] + ((old[c] + lo[c] < old[c]) ? 1ull : 0ull);
+            if (h) __hip_atomic_fetch_add(&a[2 * c + 1], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            __hip_atomic_fetch_add(&a[6], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
 }
 
 template <typename T, int W, int R, bool PROFILE>
@@ -140,14 +175,15 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
         *reinterpret_cast<uint2 *>(r + L::TAIL + 8) = uint2{0u, 0u};
     }
     if (threadIdx.x < P_arg.n_slots) { JobSlot *S0 = sh->slot(threadIdx.x, P_arg.slot_stride); S0->ready_seq = RTW_SLOT_FREE; S0->job = 0u; }
-    if (threadIdx.x < 8) sh->q[threadIdx.x] = uint2{0u, threadIdx.x == PQ_END ? (unsigned)R : 0u};
+    if (threadIdx.x < 16) sh->ctl[threadIdx.x] = threadIdx.x == 2 * PQ_END + 1 ? (unsigned)R : threadIdx.x == PC_FREE ? P_arg.n_slots : 0u;
     if (threadIdx.x == 0) {
-        sh->dead = 0u; sh->fin_waves = 0u; sh->fin_segments = 0ull; sh->fin_samples = 0ull;
-        sh->disp.lock = 0u; sh->disp.ticket = 0u; sh->disp.next = 0u; sh->disp.end = 0u; sh->disp.slot = 0u; sh->disp.b = 0u;
-        sh->disp.have_ticket = 0u; sh->disp.tk_seq = 0u; sh->disp.tk_b = 0u; sh->disp.valid = 0ull;
+        sh->fin_waves = 0u; sh->fin_segments = 0ull; sh->fin_samples = 0ull;
+        sh->disp.lock = 0u; sh->disp.next = 0u; sh->disp.end = 0u; sh->disp.slot = 0u; sh->disp.b = 0u;
+        sh->disp.have_job = 0u; sh->disp.valid = 0ull;
         sh->jobs.jc = 0ull; sh->jobs.jc_lock = 0u; sh->jobs.queue_off = 0u; sh->jobs.last_g = 0u;
         sh->cam = cam_arg; sh->P = P_arg;
     }
+    if (PROFILE && threadIdx.x < 32) sh->prof[threadIdx.x] = 0ull;
     const KParams &P = sh->P;
     stage_scene<T>(scene, lds_geom);
     for (int i = threadIdx.x; i < n_alloc; i += W * 64) lds_kind[i] = (unsigned char)(i < scene.n ? (int)scene.mat0[i].z : 0);
@@ -157,7 +193,8 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
     const T w_div = (T)(float)P.width;    // f32_image_width  (src/render.jl:16)
     const T h_div = (T)(float)P.height;   // f32_image_height (src/render.jl:17)
     PhaseClock<PROFILE> clk;
-    unsigned idle = 0;
+    unsigned long long t_kernel = 0;
+    if (PROFILE) t_kernel = __builtin_readcyclecounter();
 
 #ifdef RTW_POOL_WATCHDOG
     unsigned wd_iter = 0, wd_q = 99, wd_n = 0;
@@ -167,54 +204,68 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
         if (++wd_iter > (unsigned)RTW_POOL_WATCHDOG) {      // debug builds: dump the pool's state once and let the kernel end
             if (lane == 0 && atomicCAS(&ctr->end_hist[0], 0u, 0xdeadbeefu) == 0u) {
                 unsigned *d = ctr->end_hist + 1;
-                d[0] = blockIdx.x; d[1] = wv; d[2] = wd_q; d[3] = wd_n; d[4] = sh->dead;
-                for (int k = 0; k < PQ_COUNT; ++k) { d[5 + 2 * k] = sh->q[k].x; d[6 + 2 * k] = sh->q[k].y; }
+                d[0] = blockIdx.x; d[1] = wv; d[2] = wd_q; d[3] = wd_n; d[4] = sh->ctl[PC_DEAD];
+                for (int k = 0; k < 16; ++k) d[5 + k] = sh->ctl[k];
                 const unsigned *pd = reinterpret_cast<const unsigned *>(&sh->disp);
-                for (int k = 0; k < 12; ++k) d[20 + k] = pd[k];
+                for (int k = 0; k < 8; ++k) d[24 + k] = pd[k];
                 for (unsigned k = 0; k < P.n_slots && k < 24u; ++k) { const JobSlot *S = sh->slot(k, P.slot_stride); d[36 + 3 * k] = S->ready_seq; d[37 + 3 * k] = S->job; d[38 + 3 * k] = (unsigned)S->remaining; }
                 d[110] = sh->jobs.queue_off; d[111] = (unsigned)n_segments; d[112] = (unsigned)n_samples;
             }
-            __hip_atomic_store(&sh->dead, (unsigned)R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&sh->ctl[PC_DEAD], (unsigned)R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
         }
 #endif
+        unsigned long long t_top = 0;
+        if (PROFILE) t_top = __builtin_readcyclecounter();
         // ---- choose a stage: a queue that fills a wave (the shading stages first: the scan queue is where rays park), else the fullest ----
-        unsigned hd = 0, cnt = 0;
-        if (lane < PQ_COUNT) {
-            hd = __hip_atomic_load(&sh->q[lane].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            cnt = __hip_atomic_load(&sh->q[lane].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - hd;
-        }
-        if (uniform(__hip_atomic_load(&sh->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= (unsigned)R) break;
-        const unsigned fullm = (unsigned)__ballot(cnt >= 64u) & ((1u << PQ_WAIT) - 1u);
-        unsigned q, n;
-        if (fullm) {
-            const unsigned shading = fullm & ~1u;
-            q = shading ? (unsigned)__builtin_ctz(shading) : 0u;
-            n = 64u;
+        // lane l < 16 reads ctl[l]; lane 2q + 1 then holds queue q's tail and, one lane down, its head
+        unsigned cv = 0;
+        if (lane < 16) cv = __hip_atomic_load(&sh->ctl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned cnt = cv - (unsigned)__builtin_amdgcn_update_dpp(0, (int)cv, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+        if ((unsigned)__builtin_amdgcn_readlane((int)cv, PC_DEAD) >= (unsigned)R) break;
+        // waiting slots can be served once a job slot is free (or the job queues are exhausted: they are done)
+        const bool wait_open = ((unsigned)__builtin_amdgcn_readlane((int)cv, PC_FREE) | (unsigned)__builtin_amdgcn_readlane((int)cv, PC_EOF)) != 0u;
+        // a queue is READY when it holds its threshold: 64 for the scan (a partial scan costs a whole one), fewer for the cheap stages
+        // with a thin flow (dielectrics are 6 % of the hits: waiting for 64 of them parks slots the scan queue needs)
+        const unsigned thr = (unsigned)((RTW_POOL_THR_PACK >> (4u * (lane & 14u))) & 0xffull);        // (8 bits per queue: lane >> 1)
+        const unsigned readym = (unsigned)__ballot((lane & 1u) && lane < 2u * PQ_COUNT && cnt >= thr && (lane != 2u * PQ_WAIT + 1u || wait_open));
+        unsigned q;
+        if (readym) {
+            // the shading queues first (the scan queue is where rays park); odd waves look at them from the other end, so that
+            // waves that look at the same moment do not all reach for the same batch
+            const unsigned shading = readym & ~2u;
+            q = !shading ? 0u : (wv & 1u) ? (31u - (unsigned)__builtin_clz(shading)) >> 1 : (unsigned)__builtin_ctz(shading) >> 1;
         } else {
-            q = 0u; n = (unsigned)__builtin_amdgcn_readlane((int)cnt, 0);
-#pragma unroll
-            for (int k = 1; k < PQ_WAIT; ++k) { const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)cnt, k); if (c > n) { n = c; q = (unsigned)k; } }
-            if (n == 0u) {
-                // nothing but (perhaps) waiting slots: give the waves that hold the items a moment, then look whether a job slot is free
-                if (idle < 8u) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8);
-                idle += 1u;
-                n = (unsigned)__builtin_amdgcn_readlane((int)cnt, PQ_WAIT);
-                if (n == 0u || (idle & 3u) != 0u) continue;
-                q = PQ_WAIT; n = n > 64u ? 64u : n;
+            // No queue is ready.  While enough other waves hold batches, WAIT for them to push: a partial batch costs a stage its
+            // full instruction count and, taken greedily, keeps every queue short for good (measured: scans at 42 - 51 of 64 lanes).
+            // Only when few waves hold work -- the end of the frame, small renders -- take the fullest queue.
+            const unsigned anym = (unsigned)__ballot((lane & 1u) && lane < 2u * PQ_COUNT && cnt != 0u && (lane != 2u * PQ_WAIT + 1u || wait_open));
+            if (!anym || (unsigned)__builtin_amdgcn_readlane((int)cv, PC_BUSY) >= RTW_POOL_MIN_BUSY) {
+                __builtin_amdgcn_s_sleep(RTW_POOL_POLL);
+                if (PROFILE && lane == 0) __hip_atomic_fetch_add(&sh->prof[24], __builtin_readcyclecounter() - t_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
             }
+            q = 0u; unsigned best = 0u;
+#pragma unroll
+            for (int k = 0; k < PQ_COUNT; ++k) { const unsigned c = (anym >> (2 * k + 1)) & 1u ? (unsigned)__builtin_amdgcn_readlane((int)cnt, 2 * k + 1) : 0u; if (c > best) { best = c; q = (unsigned)k; } }
         }
+        unsigned n = (unsigned)__builtin_amdgcn_readlane((int)cnt, (int)(2u * q + 1u));
+        n = n > 64u ? 64u : n;
+        const unsigned h0 = (unsigned)__builtin_amdgcn_readlane((int)cv, (int)(2u * q));
         unsigned ok = 0;
-        if (lane == q) {
-            unsigned expect = hd;
-            ok = __hip_atomic_compare_exchange_strong(&sh->q[lane].x, &expect, hd + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+        if (lane == 0) {
+            unsigned expect = h0;
+            ok = __hip_atomic_compare_exchange_strong(&sh->ctl[2u * q], &expect, h0 + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
         }
-        if (!__builtin_amdgcn_readlane((int)ok, (int)q)) continue;              // another wave took them
-        if (q != PQ_WAIT) idle = 0u;
+        if (!uniform(ok)) {                                                     // another wave took them
+            if (PROFILE && lane == 0) __hip_atomic_fetch_add(&sh->prof[25], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        if (lane == 0) __hip_atomic_fetch_add(&sh->ctl[PC_BUSY], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef RTW_POOL_WATCHDOG
         wd_q = q; wd_n = n;
 #endif
-        const unsigned h0 = (unsigned)__builtin_amdgcn_readlane((int)hd, (int)q);
         const bool valid = lane < n;
         unsigned id = 0;
         {   // positions h0 .. h0 + n - 1 are reserved; an entry may still be on its way (its producer is between its claim and its store)
@@ -230,15 +281,23 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
             id = valid ? (e & (RTW_POOL_RING - 1u)) : 0u;
         }
         unsigned char *r = recs + id * L::BYTES;
-        auto push = [&](unsigned q2, bool pred) {
-            const unsigned long long m = __ballot(pred);
-            if (!m) return;
+        // Hand the batch's slots on: up to three destination queues, ONE LDS atomic instruction for their tails (lane j claims for
+        // destination j), then every slot's number goes to its ring cell, stamped with the cell's generation.  The store is a release:
+        // the slot's record is written before a consumer can see its number.
+        auto push3 = [&](unsigned qa, bool pa, unsigned qb, bool pb, unsigned qc, bool pc) {
+            const unsigned long long ma = __ballot(pa), mb = __ballot(pb), mc = __ballot(pc);
+            const unsigned na = (unsigned)__popcll(ma), nb = (unsigned)__popcll(mb), nc = (unsigned)__popcll(mc);
             unsigned pos = 0;
-            if (lane == 0) pos = __hip_atomic_fetch_add(&sh->q[q2].y, (unsigned)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            pos = uniform(pos);
-            if (pred) {
-                const unsigned p = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                __hip_atomic_store(rings + q2 * RTW_POOL_RING + (p & (RTW_POOL_RING - 1u)), (unsigned short)(id | (((p >> RTW_POOL_RING_SHIFT) & 31u) << RTW_POOL_RING_SHIFT)),
+            if (lane < 3) {
+                const unsigned add = lane == 0 ? na : lane == 1 ? nb : nc, qq = lane == 0 ? qa : lane == 1 ? qb : qc;
+                if (add) pos = __hip_atomic_fetch_add(&sh->ctl[2u * qq + 1u], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)pos, 0), p1 = (unsigned)__builtin_amdgcn_readlane((int)pos, 1), p2 = (unsigned)__builtin_amdgcn_readlane((int)pos, 2);
+            if (pa || pb || pc) {
+                const unsigned long long m = pa ? ma : pb ? mb : mc;
+                const unsigned p = (pa ? p0 : pb ? p1 : p2) + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const unsigned qq = pa ? qa : pb ? qb : qc;
+                __hip_atomic_store(rings + qq * RTW_POOL_RING + (p & (RTW_POOL_RING - 1u)), (unsigned short)(id | (((p >> RTW_POOL_RING_SHIFT) & 31u) << RTW_POOL_RING_SHIFT)),
                                    __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
@@ -256,9 +315,7 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
                 *reinterpret_cast<T *>(r + L::T_OFF) = t_hit;
                 *reinterpret_cast<T *>(r + L::W_OFF) = L::w_of(idx);
             }
-            push(PQ_LM, valid && idx >= 0 && kind != DIELECTRIC);
-            push(PQ_END, valid && idx < 0);
-            push(PQ_DIEL, valid && idx >= 0 && kind == DIELECTRIC);
+            push3(PQ_LM, valid && idx >= 0 && kind != DIELECTRIC, PQ_END, valid && idx < 0, PQ_DIEL, valid && idx >= 0 && kind == DIELECTRIC);
             clk.lap(2);
         } else if (q == PQ_LM || q == PQ_REJ) {
             // ---- Lambertian / Metal scatter (src/material.jl:13-34).  LM: shade the hit, then the first trials of the unit-ball
@@ -316,9 +373,7 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
                 *reinterpret_cast<ulonglong2 *>(r + L::RNG) = ulonglong2{rng.x, rng.y};
                 if (q == PQ_LM) *reinterpret_cast<uint2 *>(r + L::TAIL + 8) = uint2{ref_depth, misc};
             }
-            push(PQ_SCAN, done && has_ray);
-            push(PQ_REJ, valid && !done);
-            push(PQ_END, done && !has_ray);
+            push3(PQ_SCAN, done && has_ray, PQ_REJ, valid && !done, PQ_END, done && !has_ray);
             clk.lap(3);
         } else if (q == PQ_DIEL) {
             // ---- Dielectric scatter (src/material.jl:41-53): attenuation 1, at most one draw ----
@@ -345,8 +400,7 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
                 *reinterpret_cast<ulonglong2 *>(r + L::RNG) = ulonglong2{rng.x, rng.y};
                 *reinterpret_cast<unsigned *>(r + L::TAIL + 8) = ref_depth;
             }
-            push(PQ_SCAN, valid && has_ray);
-            push(PQ_END, valid && !has_ray);
+            push3(PQ_SCAN, valid && has_ray, PQ_END, valid && !has_ray, PQ_END, false);
             clk.lap(3);
         } else {
             // ---- END: a miss adds thr * sky to its pixel EXACTLY (src/ray_color.jl:36; a path out of depth adds nothing); finished
@@ -362,7 +416,7 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
             if (valid && L::i_of(w_) == -1) {
                 const C3 sky = skycolor(rd);
                 const unsigned item_ref = ref_depth & RTW_REF_MASK;
-                fx_accumulate(sh->slot(item_ref >> 4, P.slot_stride)->acc(item_ref & 15u), t01.x * sky.r, t01.y * sky.g, t2 * sky.b);
+                fx_accumulate3(sh->slot(item_ref >> 4, P.slot_stride)->acc(item_ref & 15u), t01.x * sky.r, t01.y * sky.g, t2 * sky.b);
             }
             unsigned samples_left = misc & RTW_PM_SAMPLES;
             bool jitter = (misc & RTW_PM_JITTER) != 0u, have_item = (misc & RTW_PM_ITEM) != 0u;
@@ -383,6 +437,7 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
                     JobSlot *S = sh->slot(uniform((unsigned)__shfl((int)((ref_depth & RTW_REF_MASK) >> 4), Lf)), P.slot_stride);
                     store_job<T>(P, S, lane, out);
                     __hip_atomic_store(&S->ready_seq, RTW_SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (lane == 0) __hip_atomic_fetch_add(&sh->ctl[PC_FREE], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 // items from the workgroup's dispenser (trace_kernel's ticket / slot protocol, under a lock)
 #pragma unroll 1
@@ -407,46 +462,50 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
                     unsigned long long d_valid = __hip_atomic_load(&D->valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     bool stop = false;
                     if (d_next >= d_end) {
-                        unsigned have_ticket = uniform(__hip_atomic_load(&D->have_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        unsigned tk_seq = uniform(__hip_atomic_load(&D->tk_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        unsigned tk_b = uniform(__hip_atomic_load(&D->tk_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        if (!have_ticket) {
-                            const unsigned t = uniform(__hip_atomic_load(&D->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                            if (lane == 0) __hip_atomic_store(&D->ticket, t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            tk_seq = udiv_magic(t, P.div_bpj_m, P.div_bpj_s);
-                            tk_b = t - tk_seq * P.bpj;
-                            have_ticket = 1u;
-                        }
-                        const unsigned sl = tk_seq - udiv_magic(tk_seq, P.div_slots_m, P.div_slots_s) * P.n_slots;   // tk_seq mod n_slots
-                        JobSlot *S = sh->slot(sl, P.slot_stride);
-                        unsigned rs = uniform(__hip_atomic_load(&S->ready_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        if (rs == RTW_SLOT_FREE && tk_b == 0u) {
-                            // (only the lock holder opens jobs: the slot is ours)
-                            if (lane == 0) __hip_atomic_store(&S->ready_seq, RTW_SLOT_OPENING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            open_job(P, S, lane, ctr, &sh->jobs);
-                            __hip_atomic_store(&S->ready_seq, tk_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            rs = tk_seq;
-                        }
-                        stop = true;                            // (unless a batch becomes available below)
-                        if (rs < RTW_SLOT_OPENING) {
-                            if (uniform(__hip_atomic_load(&S->job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == RTW_JOB_EOF) {
-                                // the job queues are exhausted (this slot stays marked for good): these slots are done
-                                if (want) dying = true;
-                                have_ticket = 0u;
-                            } else if (rs == tk_seq) {
-                                d_slot = sl; d_b = tk_b; d_next = 0u; d_end = 64u;
-                                have_ticket = 0u;
-                                const unsigned px = lane & ((1u << P.job_shift) - 1u), ch = tk_b * (64u >> P.job_shift) + (lane >> P.job_shift);
-                                d_valid = __ballot((int)ch < P.n_chunks && ((S->valid >> px) & 1u));
-                                stop = false;
+                        // the batch is used up: the next batch of the job being dispensed, or a new job in any free job slot
+                        unsigned have_job = uniform(__hip_atomic_load(&D->have_job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        const unsigned eof = uniform(__hip_atomic_load(&sh->ctl[PC_EOF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        bool have_batch = false;
+                        stop = true;
+                        if (eof) {
+                            if (want) dying = true;                 // the job queues are exhausted: these slots are done
+                        } else if (have_job && d_b + 1u < P.bpj) {
+                            d_b += 1u; have_batch = true;
+                        } else {
+                            have_job = 0u;
+                            unsigned rs = 0u;
+                            if (lane < P.n_slots) rs = __hip_atomic_load(&sh->slot(lane, P.slot_stride)->ready_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const unsigned long long free_m = __ballot(lane < P.n_slots && rs == RTW_SLOT_FREE);
+                            if (free_m) {
+                                const unsigned sl = (unsigned)__builtin_ctzll(free_m);
+                                JobSlot *S = sh->slot(sl, P.slot_stride);
+                                if (lane == 0) __hip_atomic_store(&S->ready_seq, RTW_SLOT_OPENING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                open_job(P, S, lane, ctr, &sh->jobs);
+                                if (uniform(__hip_atomic_load(&S->job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == RTW_JOB_EOF) {
+                                    if (lane == 0) {
+                                        __hip_atomic_store(&S->ready_seq, RTW_SLOT_FREE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        __hip_atomic_store(&sh->ctl[PC_EOF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    }
+                                    if (want) dying = true;
+                                } else {
+                                    if (lane == 0) {
+                                        __hip_atomic_store(&S->ready_seq, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // in flight
+                                        __hip_atomic_fetch_sub(&sh->ctl[PC_FREE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    }
+                                    d_slot = sl; d_b = 0u; have_job = 1u; have_batch = true;
+                                }
+                            } else {
+                                blocked = want;                     // every job slot holds a job in flight: wait for one to retire
                             }
-                            else blocked = want;     // the slot still holds an older job in flight -- try again later
-                        } else blocked = want;
-                        if (lane == 0) {
-                            __hip_atomic_store(&D->have_ticket, have_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_store(&D->tk_seq, tk_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_store(&D->tk_b, tk_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
+                        if (have_batch) {
+                            const JobSlot *S = sh->slot(d_slot, P.slot_stride);
+                            const unsigned px = lane & ((1u << P.job_shift) - 1u), ch = d_b * (64u >> P.job_shift) + (lane >> P.job_shift);
+                            d_valid = __ballot((int)ch < P.n_chunks && ((S->valid >> px) & 1u));
+                            d_next = 0u; d_end = 64u;
+                            stop = false;
+                        }
+                        if (lane == 0) __hip_atomic_store(&D->have_job, have_job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     if (d_next < d_end) {
                         // item p of the batch = (pixel p mod job_px, chunk (64 / job_px) b + p / job_px)
@@ -483,7 +542,7 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
                 }
                 if (got) rng_stream(P.seed, pix, chunk, rng);
                 const unsigned nd = (unsigned)__popcll(__ballot(dying));
-                if (nd && lane == 0) __hip_atomic_fetch_add(&sh->dead, nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (nd && lane == 0) __hip_atomic_fetch_add(&sh->ctl[PC_DEAD], nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // the next sample: jitter, lens disk (src/rand.jl:31-38), camera ray (src/camera.jl:43-48)
             const bool ns = valid && !dying && samples_left > 0u;
@@ -532,13 +591,22 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
                 *reinterpret_cast<double *>(r + L::TAIL) = t2;
                 *reinterpret_cast<uint2 *>(r + L::TAIL + 8) = uint2{ref_depth, misc};
             }
-            push(PQ_SCAN, ns && has_ray);
-            push(PQ_END, valid && !dying && !(ns && has_ray) && !(blocked && !ns));
-            push(PQ_WAIT, valid && !dying && blocked && !ns);
+            push3(PQ_SCAN, ns && has_ray, PQ_END, valid && !dying && !(ns && has_ray) && !(blocked && !ns), PQ_WAIT, valid && !dying && blocked && !ns);
             clk.lap(0);
+        }
+        if (lane == 0) __hip_atomic_fetch_sub(&sh->ctl[PC_BUSY], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (PROFILE && lane == 0) {
+            __hip_atomic_fetch_add(&sh->prof[4u * q], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sh->prof[4u * q + 1u], (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sh->prof[4u * q + 2u], __builtin_readcyclecounter() - t_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 
+    if (PROFILE && lane == 0) {
+        __hip_atomic_fetch_add(&sh->prof[26], __builtin_readcyclecounter() - t_kernel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sh->prof[27], clk.acc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (wave, block) evaluations without any candidate
+        __hip_atomic_fetch_add(&sh->prof[28], clk.acc[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // ... of all
+    }
     if (lane == 0) {
         __hip_atomic_fetch_add(&sh->fin_segments, n_segments, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&sh->fin_samples, n_samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -546,6 +614,10 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
             atomicAdd(&ctr->segments, __hip_atomic_load(&sh->fin_segments, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             atomicAdd(&ctr->samples, __hip_atomic_load(&sh->fin_samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             atomicAdd(&ctr->n_waves, (unsigned long long)W);
+            if (PROFILE) {
+                unsigned long long *gp = reinterpret_cast<unsigned long long *>(ctr->end_hist + 256);
+                for (int k = 0; k < 32; ++k) atomicAdd(&gp[k], __hip_atomic_load(&sh->prof[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            }
         }
     }
 }

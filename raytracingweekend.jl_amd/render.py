@@ -23,12 +23,12 @@ def _as_image(flat, height, width):
 
 
 def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chunks=0, device=-1, gamma=True,
-           group_cull=False, devices=None, scan_valu=False, lane_loop=False):
+           group_cull=False, devices=None, scan_valu=False, ray_pool=False):
     """Render ``scene`` through ``cam``; returns ``img[i, j, :]`` (row i, column j, RGB) of the
     camera's element type, memory-identical to the reference's ``Matrix{RGB{T}}``.
     ``group_cull=True`` selects the opt-in accelerated scan (same image, include/rtw_hip.h);
     ``scan_valu=True`` the all-VALU plain scan (RTW_FLAG_SCAN_VALU: same image, for A/B measurements);
-    ``lane_loop=True`` the round-3 kernel in which a lane keeps its ray (RTW_FLAG_LANE_LOOP: same image; default is the ray-pool kernel).
+    ``ray_pool=True`` the ray-pool kernel (RTW_FLAG_RAY_POOL: rays parked in LDS between stages; same image, 14 % slower).
     ``devices``: ``"all"`` or a list of HIP ordinals -- the 8x8 tiles are dealt to those devices
     inside the library (``rtw_params.n_devices/device_ids``); the image is the same for any list."""
     if not isinstance(cam, Camera):
@@ -45,7 +45,7 @@ def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chun
     Cm = _capi.make_camera(cam, T)
     P = _capi.make_params(image_width, height, n_samples, depth, seed, n_chunks, 0, 1, device, 1 if gamma else 0,
                            (_capi.FLAG_GROUP_CULL if group_cull else 0) | (_capi.FLAG_SCAN_VALU if scan_valu else 0) |
-                           (_capi.FLAG_LANE_LOOP if lane_loop else 0), devices=devices)
+                           (_capi.FLAG_RAY_POOL if ray_pool else 0), devices=devices)
     out = np.empty(height * int(image_width) * 3, dtype=T)
     fn = L.rtw_render_f64 if _capi.is_f64(T) else L.rtw_render_f32
     _capi.check(fn(C.byref(S), C.byref(Cm), C.byref(P), out.ctypes.data_as(C.c_void_p)))
@@ -80,7 +80,7 @@ class DeviceRenderer:
 
     def render_into(self, d_out_ptr, image_width, n_samples, *, depth=16, seed=1, n_chunks=0,
                     shard_index=0, shard_count=1, stream=0, gamma=True, group_cull=False, compact=False,
-                    scan_valu=False, n_elems=None, lane_loop=False, job_pixels=0):
+                    scan_valu=False, n_elems=None, ray_pool=False, job_pixels=0):
         """Enqueue one render into device memory at ``d_out_ptr``: H*W*3 elements, or with
         ``compact=True`` only this shard's tiles (``shard.compact_elems`` elements -- whole 8x8 tiles, which for a ragged
         frame can exceed H*W*3), tile-major.  ``n_elems``: the buffer's length in elements; checked when given."""
@@ -91,7 +91,7 @@ class DeviceRenderer:
             if int(n_elems) < need:
                 raise ValueError(f"output buffer holds {n_elems} elements, this render writes {need}")
         flags = ((_capi.FLAG_GROUP_CULL if group_cull else 0) | (_capi.FLAG_COMPACT_TILES if compact else 0) |
-                 (_capi.FLAG_SCAN_VALU if scan_valu else 0) | (_capi.FLAG_LANE_LOOP if lane_loop else 0))
+                 (_capi.FLAG_SCAN_VALU if scan_valu else 0) | (_capi.FLAG_RAY_POOL if ray_pool else 0))
         P = _capi.make_params(image_width, height, n_samples, depth, seed, n_chunks, shard_index, shard_count,
                               -1, 1 if gamma else 0, flags, job_pixels=job_pixels)
         fn = self.L.rtw_render_device_f64 if _capi.is_f64(self.T) else self.L.rtw_render_device_f32

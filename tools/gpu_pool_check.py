@@ -18,7 +18,7 @@ def one(W, spp, depth, scene_fn=None, cam_fn=None, reps=2):
     for mode in ("lane", "pool"):
         fb = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda:0")
         for rep in range(reps):
-            rd.render_into(fb.data_ptr(), W, spp, depth=depth, seed=1, stream=st.cuda_stream, lane_loop=(mode == "lane"))
+            rd.render_into(fb.data_ptr(), W, spp, depth=depth, seed=1, stream=st.cuda_stream, ray_pool=(mode == "pool"))
             s = rd.stats()
         out[mode] = (fb.clone(), s)
         print(f"  {mode}: kernel {s['kernel_ms']:.2f} ms  {W*H*spp/s['kernel_ms']/1e3:.1f} Msamples/s  segs {s['segments']} samples {s['samples']} grid {s['grid_blocks']}x{s['block_threads']}", flush=True)
