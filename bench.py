@@ -21,22 +21,22 @@ RTW_BENCH_ONE_DEVICE=1 (test aid for one-GPU boxes): every rank uses cuda:0 and 
 gloo -- exercises the N > 1 control flow (sharding, collective, max-over-ranks timing), not RCCL itself.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline     -- roofline of the only kernel (rtw::trace_kernel): achieved = algorithmic flops =
-                  counted ray-sphere tests x 17 flop (/root/reference/src/hit.jl:13-19)
-                  divided by the kernel's HIP-event time on its launch stream.  The every-ray-
-                  every-sphere part that this count measures runs as a conservative f16-split filter
-                  on the matrix pipe: ONE K = 32 contraction (two chained v_mfma_f32_32x32x16_f16) per
-                  32 spheres x 32 rays gives the whole filter value, the VALU adds one v_alignbit per
-                  test; the exact contract arithmetic (FP32 / FP64) runs only on the
-                  filter's candidates.  A SIMD issues EITHER an MFMA or a VALU instruction (measured:
-                  tools/ubench_mfma_pipe.hip), so `peak` is the issue bound of that formulation from the
-                  guide's cycle counts: 4 MFMA cycles + 1 VALU x 2 cycles per 64 tests -> 445.6
-                  algorithmic TFLOP/s.  `frac_fp32_vector` relates the same achieved figure to the
-                  157.3 TF vector peak of SURVEY 8(d) (it exceeds 1: the 17 flop are not executed as
-                  vector flops), `overlap_bound` to what a chip that overlapped MFMA and VALU issue
-                  would allow, `mfma_f16` gives the executed matrix-pipe flops against the 2.5 PF
-                  dense peak.  `traffic` = HBM bytes per launch from the PMC passes kept in
-                  profiles/ (static: not measured in this run), plus the algorithmic HBM figure.
+  roofline     -- roofline of the only kernel (rtw::trace_kernel), against FIXED hardware yard-sticks (round 4: the definitions no
+                  longer follow the kernel's formulation; DESIGN.md section 7 re-expresses rounds 1-3 in them):
+                    bound "mfma": `achieved` = EXECUTED matrix-pipe flops (counted ray-sphere tests x 64 flop: two chained
+                      v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays) / the kernel's HIP-event time, `peak` = 2500 TFLOP/s (the
+                      guide's dense f16 MFMA peak), `frac` = achieved / peak;          (all-VALU scan: bound "valu_fp32", peak 157.3)
+                    `algorithmic`: counted tests x 17 flop (/root/reference/src/hit.jl:13-19) / the same time, and that
+                      figure over 157.3 TF (`frac_fp32_vector`, SURVEY 8(d)'s definition; > 1 because pass 1 does not execute the
+                      17 flop as vector flops) and over 2500 TF;
+                    `issue_model` (a MODEL, labelled so): a SIMD issues either a 32-cycle MFMA or a VALU instruction; 4 MFMA + 1
+                      v_alignbit_b32 per 64 tests, the alignbit charged 2 cycles (the guide's FMA class) -> 445.6 algorithmic TF, or
+                      4.3 cycles (measured slow class, tools/ubench_rates.hip) -> 322.3 TF;
+                    `issue_busy`: (MFMA-busy + 2 x VALU instructions) / SIMD-cycles from the committed PMC pass (static);
+                    `traffic`: HBM bytes per launch from the PMC passes kept in profiles/ (static), plus the algorithmic HBM figure.
+  value        -- device-resident rate (scene in HBM, image left in HBM), as the task's bench contract prescribes;
+                  `value_end_to_end` is SURVEY 8(d)'s metric: the host-buffer entry point rtw_render_* timed the same way (barrier +
+                  synchronize around K calls; render + D2H of the image into the caller's buffer; scene upload cached by the library).
   scan_valu    -- the same workload with RTW_FLAG_SCAN_VALU (the contract discriminant for every
                   sphere on the vector ALUs, the round-1/2 scan): same image, for comparison.
   cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
@@ -48,6 +48,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   D2H of the image: the PCIe-inclusive rate; never `value`).
   depth16      -- the same workload at the reference's own depth (src/ray_color.jl:14).
   f64_4k       -- configs[4]'s single-GPU share (3840x2160, Float64), with its own roofline and cpu_baseline.
+  f64_1080p_d16 -- the reference's PUBLISHED configuration (Float64, 1920x1080, 1000 spp, depth 16: README.md:86,118-119,
+                  1.617 Msamples/s on a Ryzen 3700 -- different hardware), with its own roofline, cpu_baseline and `vs_published`.
+  N > 1        -- `render_ms_max` / `render_ms_min` (per-rank kernel time, mean over the steps) and `collective_ms` (HIP events around
+                  the one collective on rank 0's stream, mean over the steps): a bad scaling point can be attributed.
 """
 import argparse
 import hashlib
@@ -72,8 +76,11 @@ HBM_PEAK_GBS = 8000.0
 FLOP_PER_TEST = 17              # 3 sub + 5 + 5 (dots) + mul/sub + mul/sub, src/hit.jl:13-19
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
 MFMA_CYCLES_PER_64_TESTS = 4.0  # 4 MFMAs x 32 cycles per block of 32 spheres x 64 rays (2048 tests)
-VALU_CYCLES_PER_64_TESTS = 2.0  # one v_alignbit_b32 per test = one wave instruction per 64 tests, 2 cycles/SIMD (guide: v_fma_f32 class)
-TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
+ALIGNBIT_CYCLES = {"alignbit_2_cycles": 2.0,      # one v_alignbit_b32 per test: the guide's FMA-class issue cost ...
+                   "alignbit_4p3_cycles": 4.3}    # ... and the slow-class cost measured on this chip (tools/ubench_rates.hip)
+TRAFFIC_FILE = os.path.join("profiles", "r04_hbm_traffic.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc_summary.json")
+PUBLISHED_MSAMPLES = 1.617      # /root/reference/README.md:86,118-119: 1282.44 s for 1920x1080x1000 spp, Float64, depth 16, 16 threads, Ryzen 3700
 
 
 def parse_args(argv=None):
@@ -195,11 +202,14 @@ class Workload:
         self.renderer.close()
         self.fb = None
 
-    def timed(self, n_steps, n_warm, *, cull, depth, record=None, valu=False):
-        """n_warm untimed + n_steps timed steps bracketed by barrier + synchronize; returns max-over-ranks seconds."""
+    def timed(self, n_steps, n_warm, *, cull, depth, record=None, valu=False, coll_ms=None):
+        """n_warm untimed + n_steps timed steps bracketed by barrier + synchronize; returns max-over-ranks seconds.
+        `coll_ms` (a list): per timed step, the HIP-event time between the end of this rank's render and the end of the collective."""
         c, a = self.c, self.c.args
+        torch = c.torch
+        evs = []
 
-        def step(rec):
+        def step(rec, timed_step):
             def shard(idx, cnt):
                 if a.emulate_shard_of > 1:
                     idx, cnt = 0, a.emulate_shard_of
@@ -207,22 +217,53 @@ class Workload:
                                           shard_count=cnt, stream=c.stream.cuda_stream, group_cull=cull,
                                           compact=a.collective == "gather", scan_valu=valu and not cull, n_elems=self.fb.numel())
                 return self.fb
-            self.frame = c.R.render_sharded(shard, self.W, mode=a.collective)    # this rank's tiles, ONE collective onto rank 0
+            hook = None
+            if timed_step and coll_ms is not None and c.world > 1:
+                e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                hook = lambda: e1.record(c.stream)
+            self.frame = c.R.render_sharded(shard, self.W, mode=a.collective, after_render=hook)    # this rank's tiles, ONE collective onto rank 0
+            if hook is not None:
+                e2.record(c.stream)
+                evs.append((e1, e2))
             if rec is not None:
                 rec.append(self.renderer.stats())               # waits for this rank's kernel (HIP events on `stream`)
         for _ in range(n_warm):
-            step(None)
+            step(None, False)
         fence(c)
         t0 = time.perf_counter()
         for _ in range(n_steps):
-            step(record)
+            step(record, True)
         fence(c)
         dt = time.perf_counter() - t0
         if c.world > 1:
-            tmax = c.torch.tensor([dt], dtype=c.torch.float64, device=c.dev)
+            tmax = torch.tensor([dt], dtype=torch.float64, device=c.dev)
             c.dist.all_reduce(tmax, op=c.dist.ReduceOp.MAX)
             dt = float(tmax.item())
+        if coll_ms is not None:
+            coll_ms.extend(e1.elapsed_time(e2) for e1, e2 in evs)
         return dt
+
+    def timed_host(self, n_steps, n_warm, *, cull, depth, valu=False):
+        """SURVEY 8(d)'s metric: K calls of the host-buffer entry point (what the Julia ccall binds: render + D2H of the image into
+        the caller's buffer, blocking; the scene upload is cached by the library between calls), barrier + synchronize around them."""
+        c, a = self.c, self.c.args
+        k_ms = []
+
+        def call():
+            c.R.render(self.scene, self.cam, self.W, self.spp, depth=depth, seed=1, n_chunks=a.chunks, device=c.local_rank,
+                       group_cull=cull, scan_valu=valu and not cull)
+            k_ms.append(c.R.last_stats()["kernel_ms"])
+        t = time.perf_counter()
+        call()                                                  # the first call of a scene builds the library's per-device context
+        first_ms = (time.perf_counter() - t) * 1e3
+        for _ in range(max(0, n_warm - 1)):
+            call()
+        fence(c)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            call()
+        fence(c)
+        return time.perf_counter() - t0, first_ms, k_ms[-n_steps:]
 
     def frame_sha256(self):
         """SHA-256 of the assembled H x W x 3 frame of the last step (rank 0; outside every timed region)."""
@@ -231,55 +272,79 @@ class Workload:
         return hashlib.sha256(host.tobytes()).hexdigest()
 
 
+def issue_busy_from_pmc(key):
+    """(MFMA-busy cycles + 2 x VALU instructions) / SIMD-cycles of the committed PMC pass of this workload (static)."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        a, m = pm["pmc_%s_sqA" % key]["counters"], pm["pmc_%s_mfma" % key]["counters"]
+        simd = N_SIMD * a["GRBM_GUI_ACTIVE"] / 8
+        return {"mfma_busy": round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / simd, 4), "valu_x2": round(2 * a["SQ_INSTS_VALU"] / simd, 4),
+                "sum": round((m["SQ_VALU_MFMA_BUSY_CYCLES"] + 2 * a["SQ_INSTS_VALU"]) / simd, 4),
+                "source": PMC_FILE + " (rocprofv3 --pmc passes of this command, one launch each; static: not measured in this run)"}
+    except Exception:
+        return None
+
+
 def roofline_of(wl, k_s, tests_per_launch, seg_per_sample, *, cull, valu, world, shard_div):
-    args = wl.c.args
+    """Fixed yard-sticks (round 4): the guide's dense f16 MFMA peak for the executed matrix-pipe flops, the FP32 vector peak of SURVEY 8(d)
+    for the algorithmic 17 flop per test; the issue model is reported as a model, with both costs of the alignbit."""
     W, H, spp, depth = wl.W, wl.H, wl.spp, wl.depth
-    issue_peak = N_SIMD * CLOCK_HZ / (MFMA_CYCLES_PER_64_TESTS + VALU_CYCLES_PER_64_TESTS) * 64 * FLOP_PER_TEST / 1e12
-    overlap_peak = N_SIMD * CLOCK_HZ / max(MFMA_CYCLES_PER_64_TESTS, VALU_CYCLES_PER_64_TESTS) * 64 * FLOP_PER_TEST / 1e12
-    peak = issue_peak if not valu else VALU_PEAK_TFLOPS[wl.dtype]
-    achieved = tests_per_launch * FLOP_PER_TEST / k_s / 1e12
+    algorithmic = tests_per_launch * FLOP_PER_TEST / k_s / 1e12
     mfma_tflops = tests_per_launch * MFMA_FLOP_PER_TEST / k_s / 1e12
     esize = 8 if wl.dtype == "f64" else 4
     alg_bytes = W * H * 3 * esize / world / shard_div + wl.n_spheres * 12 * esize   # framebuffer write + one scene read
     # HBM bytes per launch from the PMC passes kept under profiles/ (separate --pmc runs of this same command): static,
     # valid for the exact workload they were taken on -- rocprofv3 counters cannot be read from inside this process
     traffic = traffic_src = None
+    mode = "cull" if cull else ("valu" if valu else "plain")
     try:
         tr = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
-        key = f"{wl.dtype}_{W}x{H}_{spp}spp_d{depth}_{'cull' if cull else ('valu' if valu else 'plain')}"
+        key = f"{wl.dtype}_{W}x{H}_{spp}spp_d{depth}_{mode}"
         if world == 1 and shard_div == 1 and key in tr:
             traffic, traffic_src = tr[key]["hbm_bytes_per_launch"], tr[key].get("source")
     except Exception:
         pass
     matrix = not (cull or valu)
+    vpeak = VALU_PEAK_TFLOPS[wl.dtype]
+    issue = None
+    if matrix:
+        issue = {"model": True, "what": "a SIMD issues EITHER a 32-cycle v_mfma_f32_32x32x16_f16 or a VALU instruction (no overlap on gfx950: tools/ubench_mfma_pipe.hip); "
+                                        "per 64 tests 4 MFMA cycles + one v_alignbit_b32"}
+        for name, cyc in ALIGNBIT_CYCLES.items():
+            pk = N_SIMD * CLOCK_HZ / (MFMA_CYCLES_PER_64_TESTS + cyc) * 64 * FLOP_PER_TEST / 1e12
+            issue[name] = {"peak_algorithmic_TFLOPs": round(pk, 1), "frac": round(algorithmic / pk, 4)}
+    headline = (wl.dtype, W, spp, depth) == ("f32", 1920, 1000, 50) and world == 1 and shard_div == 1
+    if cull:
+        bound, achieved, peak = "mfma", None, MFMA_F16_PEAK_TFLOPS
+    elif valu:
+        bound, achieved, peak = "valu_" + ("fp64" if wl.dtype == "f64" else "fp32"), algorithmic, vpeak
+    else:
+        bound, achieved, peak = "mfma", mfma_tflops, MFMA_F16_PEAK_TFLOPS
     return {
-        "bound": ("valu_" + ("fp64" if wl.dtype == "f64" else "fp32")) if valu else "mfma",
-        "bound_detail": None if not matrix else "SIMD issue time shared by v_mfma_f32_32x32x16_f16 (32 cycles each) and VALU (2 cycles each): no overlap on gfx950",
+        "bound": bound,
         "kernel": f"rtw::trace_kernel<{'double' if wl.dtype == 'f64' else 'float'}>",
-        "achieved": None if cull else round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-        "frac": None if cull else round(achieved / peak, 4),
-        "peak_derivation": None if not matrix else
-            "1024 SIMDs x 2.4 GHz / (4 MFMA + 2 VALU cycles per 64 tests) x 64 tests x 17 algorithmic flop (cycle counts: MI355X_MICROARCH.md); "
-            "rounds 1-2 used 157.3 (all-VALU scan) and 334.2 (two products + fma + alignbit: 4 + 4 cycles)",
-        "frac_fp32_vector": None if cull else round(achieved / VALU_PEAK_TFLOPS["f32"], 4),
-        "fp32_vector_peak": VALU_PEAK_TFLOPS["f32"],
-        "overlap_bound": None if not matrix else {"peak": round(overlap_peak, 1), "frac": round(achieved / overlap_peak, 4),
-                                                   "note": "if MFMA and VALU issue overlapped perfectly (they do not on this chip)"},
+        "achieved": None if achieved is None else round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": None if achieved is None else round(achieved / peak, 4),
+        "definition": None if not matrix else "achieved = EXECUTED f16 matrix-pipe flops (counted ray-sphere tests x 64: two chained v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays) / "
+                                              "kernel time; peak = dense f16 MFMA peak of MI355X_MICROARCH.md (fixed since round 4)",
+        "algorithmic": None if cull else {"flop_per_test": FLOP_PER_TEST, "achieved": round(algorithmic, 3), "unit": "TFLOP/s",
+                                          "frac_fp32_vector": round(algorithmic / VALU_PEAK_TFLOPS["f32"], 4), "fp32_vector_peak": VALU_PEAK_TFLOPS["f32"],
+                                          "frac_mfma_f16_peak": round(algorithmic / MFMA_F16_PEAK_TFLOPS, 4),
+                                          "note": "SURVEY 8(d): counted tests x 17 flop / kernel time; > 1 of the FP32 vector peak because pass 1 (a conservative "
+                                                  "bilinear filter on the matrix pipe) does not execute the 17 flop as vector flops -- the exact 17-flop test runs on its candidates only"},
+        "issue_model": issue,
+        "issue_busy": issue_busy_from_pmc("f32") if (matrix and headline) else None,
         "traffic": traffic, "traffic_static": True,
         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this command; read from " + TRAFFIC_FILE + ")",
         "traffic_source": traffic_src,
-        "kernel_ms": round(k_s * 1e3, 3), "tests_per_launch": int(tests_per_launch),
-        "flop_per_test": FLOP_PER_TEST, "segments_per_sample": round(seg_per_sample, 4),
-        "mfma_f16": None if not matrix else {"executed_flop_per_test": MFMA_FLOP_PER_TEST, "achieved": round(mfma_tflops, 1),
-                                              "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_tflops / MFMA_F16_PEAK_TFLOPS, 4)},
-        "valu": None if not matrix else {"instructions_per_test": 1, "what": "v_alignbit_b32 (sign bit of the filter value into the candidate mask)"},
-        "note": "achieved = counted ray-sphere tests x 17 algorithmic flop / kernel time.  Every sphere is tested against every ray segment, but "
-                "pass 1 of the scan is a conservative FILTER: D = (d.c)^2 + 2 p.c + (q^2 - |o|^2) + (r^2 - |c|^2) is bilinear in (ray features) x "
-                "(sphere features), so one K = 32 contraction over f16-split features (two chained v_mfma_f32_32x32x16_f16) evaluates 32 spheres x 32 "
-                "rays and the VALU adds one alignbit per test (rigorous margin, DESIGN.md 6.1); the exact contract arithmetic (17 flop, FP32 or FP64) "
-                "runs only on the filter's candidates.  `scan_valu` is the same workload with every test on the vector ALUs."
+        "kernel_ms": round(k_s * 1e3, 3), "tests_per_launch": int(tests_per_launch), "segments_per_sample": round(seg_per_sample, 4),
+        "note": "Every sphere is tested against every ray segment, but pass 1 of the scan is a conservative FILTER: D = (d.c)^2 + 2 p.c + (q^2 - |o|^2) + "
+                "(r^2 - |c|^2) is bilinear in (ray features) x (sphere features), so one K = 32 contraction over f16-split features evaluates 32 spheres x 32 "
+                "rays and the VALU adds one alignbit per test (rigorous margin, DESIGN.md 6.1); the exact contract arithmetic (FP32 or FP64) runs only on "
+                "the filter's candidates.  `scan_valu` is the same workload with every test on the vector ALUs."
                 if matrix else
-                ("all-VALU plain scan (RTW_FLAG_SCAN_VALU): 11 instructions per test (Float32) / 13 binary32 filter instructions (Float64)"
+                ("all-VALU plain scan (RTW_FLAG_SCAN_VALU): 11 instructions per test (Float32) / 13 binary32 filter instructions (Float64); "
+                 "achieved = counted tests x 17 flop / kernel time"
                  if valu else "group-cull mode: tests are skipped, no roofline fraction"),
         "hbm": {"algorithmic_bytes": int(alg_bytes), "achieved_GBs": round(alg_bytes / k_s / 1e9, 4),
                 "peak_GBs": HBM_PEAK_GBS, "frac": round(alg_bytes / k_s / 1e9 / HBM_PEAK_GBS, 8)},
@@ -327,8 +392,8 @@ def main():
 
     wl = Workload(c, args.dtype, args.width, args.spp, args.depth)
     W, H, spp, depth = wl.W, wl.H, wl.spp, wl.depth
-    stats = []
-    dt = wl.timed(args.steps, args.warmup, cull=args.group_cull, depth=depth, record=stats, valu=args.scan_valu)
+    stats, coll = [], []
+    dt = wl.timed(args.steps, args.warmup, cull=args.group_cull, depth=depth, record=stats, valu=args.scan_valu, coll_ms=coll)
     sha = wl.frame_sha256() if rank == 0 else None
     kernel_ms = [s["kernel_ms"] for s in stats]
     tests = [s["sphere_tests"] for s in stats]
@@ -338,10 +403,11 @@ def main():
         agg = torch.tensor([sum(tests), sum(segments)], dtype=torch.float64, device=c.dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         all_segments = float(agg[1])
-        mine = torch.tensor([sum(kernel_ms) / len(kernel_ms), float(c.local_rank)], dtype=torch.float64, device=c.dev)
+        mine = torch.tensor([sum(kernel_ms) / len(kernel_ms), float(c.local_rank), sum(coll) / max(1, len(coll))], dtype=torch.float64, device=c.dev)
         allk = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allk, mine)
-        per_rank = [{"rank": r, "device": int(t[1].item()), "kernel_ms": round(float(t[0].item()), 3)} for r, t in enumerate(allk)]
+        per_rank = [{"rank": r, "device": int(t[1].item()), "kernel_ms": round(float(t[0].item()), 3), "collective_ms": round(float(t[2].item()), 3)}
+                    for r, t in enumerate(allk)]
     else:
         all_segments = float(sum(segments))
 
@@ -350,7 +416,7 @@ def main():
     value = samples_per_step * args.steps / dt / 1e6
 
     extras = not args.no_extras and args.emulate_shard_of <= 1
-    accel = depth16 = scan_valu = end_to_end = f64_4k = None
+    accel = depth16 = scan_valu = end_to_end = f64_4k = f64_pub = None
     if extras and not args.group_cull:
         # the opt-in accelerated scan (RTW_FLAG_GROUP_CULL, bit-identical image), timed the same way, reported
         # separately: `value` stays the reference's plain linear scan so that the roofline figure means what it says
@@ -369,21 +435,16 @@ def main():
         depth16 = {"value": round(samples_per_step / dt16 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt16 * 1e3, 3),
                    "segments_per_sample": round(st16[0]["segments"] * world / samples_per_step, 4) if world == 1 else None,
                    "note": "same workload at depth 16, the reference's only depth (src/ray_color.jl:14)"}
-    if extras and world == 1:
-        # host-buffer entry point, what the Julia ccall binds: scene upload + render + image D2H, blocking.
-        # Twice: the first call builds the library's per-device context (scene, stream, device image, pinned staging), the
-        # second one reuses it -- what a caller that renders frame after frame pays.
-        e2e = []
-        for _ in range(2):
-            t = time.perf_counter()
-            R.render(wl.scene, wl.cam, W, spp, depth=depth, seed=1, n_chunks=args.chunks, device=c.local_rank, group_cull=args.group_cull,
-                     scan_valu=args.scan_valu)
-            e2e.append((time.perf_counter() - t, R.last_stats()["kernel_ms"]))
-        te, tk = e2e[1]
-        end_to_end = {"value": round(W * H * spp / te / 1e6, 2), "unit": "Msamples/s", "ms": round(te * 1e3, 3),
-                      "kernel_ms": round(tk, 3), "overhead_ms": round(te * 1e3 - tk, 3),
-                      "first_call_ms": round(e2e[0][0] * 1e3, 3), "first_call_kernel_ms": round(e2e[0][1], 3),
-                      "note": "rtw_render_* on host buffers: H2D scene, render, D2H image (PCIe-inclusive); never `value`"}
+    if world == 1 and args.emulate_shard_of <= 1:
+        # SURVEY 8(d)'s metric -- the host-buffer entry point (what the Julia ccall binds): render + D2H of the image into the caller's
+        # buffer, timed like `value` (the scene upload is cached by the library: the first call, reported separately, pays it)
+        ne = args.steps if extras else 1
+        dte, first_ms, k_ms = wl.timed_host(ne, 1, cull=args.group_cull, depth=depth, valu=args.scan_valu)
+        end_to_end = {"value": round(W * H * spp * ne / dte / 1e6, 2), "unit": "Msamples/s", "steps": ne, "ms": round(dte / ne * 1e3, 3),
+                      "kernel_ms": round(sum(k_ms) / len(k_ms), 3), "overhead_ms": round(dte / ne * 1e3 - sum(k_ms) / len(k_ms), 3),
+                      "first_call_ms": round(first_ms, 3),
+                      "note": "rtw_render_* on host buffers (SURVEY 8(d)'s definition of the metric): render + D2H of the image, PCIe-inclusive, blocking; "
+                              "the scene upload is cached between calls (first_call_ms includes it)"}
 
     line = None
     if rank == 0:
@@ -401,6 +462,14 @@ def main():
             "metric": f"Msamples/s (pixels x spp) on scene_random_spheres {W}x{H}",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "value_definition": "device-resident: scene in HBM before, image left in HBM (rank 0) after the timed region -- the bench contract of the task; "
+                                "SURVEY 8(d)'s end-to-end metric (render + D2H into the caller's buffer) is `value_end_to_end`",
+            "value_end_to_end": end_to_end["value"] if end_to_end else None,
+            "kernel_only": round(samples_per_step / (sum(kernel_ms) / len(kernel_ms)) / 1e3, 2) if world == 1 else None,
+            "render_ms_max": max(r["kernel_ms"] for r in per_rank) if per_rank else round(sum(kernel_ms) / len(kernel_ms), 3),
+            "render_ms_min": min(r["kernel_ms"] for r in per_rank) if per_rank else round(sum(kernel_ms) / len(kernel_ms), 3),
+            "collective_ms": round(per_rank[0]["collective_ms"], 3) if per_rank else 0.0,
+            "collective_ms_max": max(r["collective_ms"] for r in per_rank) if per_rank else 0.0,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"scene_random_spheres ({wl.n_spheres} spheres, reseed!() seed 1), t_cam1, {W}x{H}, {spp} spp, "
                                    f"depth {depth}, {wl.jl} ({cfg_name(args.dtype, W, spp, depth, world)})",
@@ -445,8 +514,29 @@ def main():
             f64_4k["cpu_baseline"] = max(legs4, key=lambda d: d["value"])
             f64_4k["gpu_over_cpu"] = round(f64_4k["value"] / f64_4k["cpu_baseline"]["value"], 1)
         w4.close()
+        # the reference's PUBLISHED configuration (README.md:86,118-119; src/proto/proto.jl:229-230): Float64, 1920x1080, 1000 spp, depth 16
+        wp = Workload(c, "f64", 1920, 1000, 16)
+        stp = []
+        n_p = 3
+        dtp = wp.timed(n_p, 1, cull=False, depth=16, record=stp)
+        kp = sum(s["kernel_ms"] for s in stp) / len(stp) / 1e3
+        samples_p = wp.W * wp.H * 1000
+        f64_pub = {"config": {"workload": f"scene_random_spheres ({wp.n_spheres} spheres), t_cam1, 1920x1080, 1000 spp, depth 16, Float64 "
+                                          "(the configuration of the reference's only published render time, /root/reference/README.md:86,118-119)"},
+                   "value": round(samples_p * n_p / dtp / 1e6, 2), "unit": "Msamples/s", "steps": n_p, "warmup": 1, "ms_per_step": round(dtp / n_p * 1e3, 3),
+                   "dtype": "f64", "frame_sha256": wp.frame_sha256(),
+                   "roofline": roofline_of(wp, kp, sum(s["sphere_tests"] for s in stp) / len(stp),
+                                           sum(s["segments"] for s in stp) / (samples_p * n_p), cull=False, valu=False, world=1, shard_div=1)}
+        f64_pub["vs_published"] = {"published": PUBLISHED_MSAMPLES, "unit": "Msamples/s", "ratio": round(f64_pub["value"] / PUBLISHED_MSAMPLES, 1),
+                                   "published_on": "Ryzen 3700 (8C/16T), julia -t 16, 1282.44 s -- DIFFERENT HARDWARE, context only (not `vs_baseline`)"}
+        if not args.no_cpu_baseline:
+            legsp, _ = cpu_legs(wp, min(args.cpu_seconds, 8.0))
+            f64_pub["cpu_baseline"] = max(legsp, key=lambda d: d["value"])
+            f64_pub["gpu_over_cpu"] = round(f64_pub["value"] / f64_pub["cpu_baseline"]["value"], 1)
+        wp.close()
     if rank == 0:
         line["f64_4k"] = f64_4k
+        line["f64_1080p_d16"] = f64_pub
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -64,7 +64,7 @@ matparam(m::Dielectric{T}) where T = m.ir
 last_error() = unsafe_string(ccall((:rtw_last_error, LIB), Cstring, ()))
 
 """
-    render(scene, cam, image_width=400, n_samples=1; depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, group_cull=false, scan_valu=false)
+    render(scene, cam, image_width=400, n_samples=1; depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, group_cull=false, scan_valu=false, ray_pool=false)
 
 Drop-in for `RayTracingWeekend.render` (src/render.jl:8-44) on MI355X.  Keyword extras only.
 `depth=16` is the reference's hard-wired `ray_color` default (src/ray_color.jl:14).
@@ -74,7 +74,7 @@ round-robin to the devices inside the library; the image is identical for any de
 scan (RTW_FLAG_SCAN_VALU, for A/B measurements): same image bit for bit in every mode.
 """
 function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=1;
-                depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, group_cull=false, scan_valu=false) where T <: Union{Float32,Float64}
+                depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, group_cull=false, scan_valu=false, ray_pool=false) where T <: Union{Float32,Float64}
     image_height = image_width ÷ (16//9)                       # src/render.jl:11-12
     n = length(scene)
     cx = Vector{T}(undef, n); cy = similar(cx); cz = similar(cx); r = similar(cx)
@@ -94,7 +94,7 @@ function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=
     n_devices = devices === :all ? -1 : (length(ids) > 1 ? length(ids) : 0)
     length(ids) == 1 && (device = ids[1])
     rc = GC.@preserve cx cy cz r kind ar ag ab param img ids begin
-        params = Ref(CParams(image_width, image_height, n_samples, depth, seed, n_chunks, 0, 1, device, 1, (group_cull ? 1 : 0) | (scan_valu ? 4 : 0),
+        params = Ref(CParams(image_width, image_height, n_samples, depth, seed, n_chunks, 0, 1, device, 1, (group_cull ? 1 : 0) | (scan_valu ? 4 : 0) | (ray_pool ? 8 : 0),
                              n_devices, 0, length(ids) > 1 ? pointer(ids) : Ptr{Int32}(C_NULL)))
         cscene = Ref(CScene{T}(n, pointer(cx), pointer(cy), pointer(cz), pointer(r), pointer(kind),
                                pointer(ar), pointer(ag), pointer(ab), pointer(param)))

@@ -65,7 +65,7 @@ def compact_to_frame_index(image_width, shard_index, shard_count, pad_tiles=None
 _index_cache = {}
 
 
-def render_sharded(render_shard, image_width, *, group=None, dst=0, mode="reduce"):
+def render_sharded(render_shard, image_width, *, group=None, dst=0, mode="reduce", after_render=None):
     """Run this rank's shard and put the shards together on rank ``dst``.
 
     ``mode="reduce"``: ``render_shard(shard_index, shard_count) -> torch.Tensor`` returns this rank's
@@ -75,6 +75,9 @@ def render_sharded(render_shard, image_width, *, group=None, dst=0, mode="reduce
     gets the assembled frame as a flat ``H*W*3`` tensor in ``Matrix{RGB{T}}`` layout.
 
     ``dst`` is a GLOBAL rank (what ``torch.distributed.reduce/gather`` take); with a sub-``group`` it must be a member.
+
+    ``after_render`` (optional callable): called right after this rank's render has been enqueued and before the collective --
+    bench.py records a HIP event there to time the render and the collective separately.
 
     Returns the full framebuffer on rank ``dst`` and the local (partial) one elsewhere.
     ``render_shard`` is the HIP path in production (DeviceRenderer.render_into on this rank's GPU);
@@ -93,6 +96,8 @@ def render_sharded(render_shard, image_width, *, group=None, dst=0, mode="reduce
     if on and group is not None and dist.get_group_rank(group, int(dst)) < 0:
         raise ValueError(f"dst={dst} is not a member of the group")
     fb = render_shard(rank, world)
+    if after_render is not None:
+        after_render()
     if mode == "reduce":
         if world > 1:
             dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM, group=group)

@@ -112,3 +112,60 @@ def test_ray_pool_identical_at_1080p(rtw):
     assert sa["segments"] == sb["segments"] and sa["samples"] == sb["samples"] == 1920 * 1080 * 100
     assert bool(torch.equal(a, b)), int((a != b).sum())
     dr.close()
+
+
+# ---- Float64 at full scale --------------------------------------------------------------------------------------------------
+def test_three_scan_modes_identical_f64_4k(rtw):
+    """BASELINE configs[4]'s geometry -- 3840x2160, Float64, depth 50 -- at 100 spp (3.3e9 ray segments) in all three scan modes.  The
+    Float64 kernel feeds the SAME binary32 / f16 matrix-pipe filter with inputs ROUNDED from binary64 (an extra 1.5 S term of its error
+    budget, rtw_device.hpp): a candidate lost to that rounding shows against the all-VALU leg (its own conservative binary32 filter, a
+    different derivation) and the cull leg; all three share the exact binary64 contract test of the candidates."""
+    import torch
+    T = np.float64
+    rtw.reseed()
+    dr = rtw.DeviceRenderer(rtw.scene_random_spheres(elem_type=T), rtw.t_cam1(elem_type=T), device=0)
+    a = torch.empty(2160 * 3840 * 3, dtype=torch.float64, device="cuda:0")
+    b, c = torch.empty_like(a), torch.empty_like(a)
+    s = torch.cuda.current_stream()
+    dr.render_into(a.data_ptr(), 3840, 100, depth=50, seed=1, stream=s.cuda_stream)
+    sa = dr.stats()
+    dr.render_into(b.data_ptr(), 3840, 100, depth=50, seed=1, stream=s.cuda_stream, scan_valu=True)
+    sb = dr.stats()
+    dr.render_into(c.data_ptr(), 3840, 100, depth=50, seed=1, stream=s.cuda_stream, group_cull=True)
+    sc = dr.stats()
+    assert sa["segments"] == sb["segments"] == sc["segments"] and sa["samples"] == 3840 * 2160 * 100
+    assert bool(torch.equal(a, b)), int((a != b).sum())
+    assert bool(torch.equal(a, c)), int((a != c).sum())
+    dr.close()
+
+
+def test_f64_4k_8spp_against_the_live_oracle(oracle, rtw):
+    """3840x2160 x 8 spp, depth 50, Float64 (6.6e7 samples, 1.8e8 segments) against the oracle rendered here: bit-exact image and
+    segment count, plain and cull mode (round 2 compared this geometry at 1 spp)."""
+    T = np.float64
+    g, cam = _random_spheres_case(rtw, oracle, T, 3840, 8, depth=50)
+    ref, ost = oracle.render(g["flat"], cam, 3840, 2160, 8, T=T, max_depth=50, seed=1)
+    for flags in (0, FLAG_CULL):
+        img, st = gpu_render(g, flags=flags)
+        assert st.segments == ost["segments"]
+        assert np.array_equal(img, ref), int((img != ref).sum())
+
+
+def test_f64_published_configuration_modes_identical(rtw):
+    """the reference's published configuration (Float64, 1920x1080, depth 16; README.md:86) at 200 spp: three scan modes, one image"""
+    import torch
+    T = np.float64
+    rtw.reseed()
+    dr = rtw.DeviceRenderer(rtw.scene_random_spheres(elem_type=T), rtw.t_cam1(elem_type=T), device=0)
+    a = torch.empty(1080 * 1920 * 3, dtype=torch.float64, device="cuda:0")
+    b, c = torch.empty_like(a), torch.empty_like(a)
+    s = torch.cuda.current_stream()
+    dr.render_into(a.data_ptr(), 1920, 200, depth=16, seed=1, stream=s.cuda_stream)
+    sa = dr.stats()
+    dr.render_into(b.data_ptr(), 1920, 200, depth=16, seed=1, stream=s.cuda_stream, scan_valu=True)
+    sb = dr.stats()
+    dr.render_into(c.data_ptr(), 1920, 200, depth=16, seed=1, stream=s.cuda_stream, group_cull=True)
+    sc = dr.stats()
+    assert sa["segments"] == sb["segments"] == sc["segments"]
+    assert bool(torch.equal(a, b)) and bool(torch.equal(a, c))
+    dr.close()

@@ -11,7 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 import numpy as np
 
 
-def scan_rounds(seconds, seed, log=print):
+def scan_rounds(seconds, seed, log=print, max_rounds=None):
     """Random scenes (1 ... 1500 spheres, extents 1e-3 ... 1e6, both precisions) x 131 072 random rays through the matrix-pipe
     scan and its block-culling form vs the oracle.  -> (rounds, rays, mismatches, next seed)"""
     import rtw_oracle as O
@@ -19,7 +19,7 @@ def scan_rounds(seconds, seed, log=print):
     from test_gpu_round2 import _stress_scene, _stress_rays
     t0 = time.time()
     rays_total = bad_total = rounds = 0
-    while time.time() - t0 < seconds:
+    while time.time() - t0 < seconds and (max_rounds is None or rounds < max_rounds):
         rng = np.random.default_rng(seed)
         T = np.float32 if seed % 2 == 0 else np.float64
         n = int(rng.choice([1, 2, 7, 33, 64, 65, 200, 485, 600, 1500]))
@@ -41,16 +41,17 @@ def scan_rounds(seconds, seed, log=print):
     return rounds, rays_total, bad_total, seed
 
 
-def render_rounds(seconds, seed, log=print):
-    """Random small scenes / cameras rendered in all four scan modes vs the oracle.  -> (images, mismatches, next seed)"""
+def render_rounds(seconds, seed, log=print, max_rounds=None):
+    """Random small scenes / cameras rendered in all four scan modes and by the ray-pool kernel vs the oracle.  -> (images, mismatches, next seed)
+    `max_rounds`: stop after that many scenes (a reproducible amount of work for a fixed seed list)"""
     import rtw_oracle as O
     import rtw_amd as R
     from test_gpu_render import gpu_render
     from conftest import load_golden
     g0 = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
     t0 = time.time()
-    imgs = bad_imgs = 0
-    while time.time() - t0 < seconds:
+    imgs = bad_imgs = scenes = 0
+    while time.time() - t0 < seconds and (max_rounds is None or scenes < max_rounds):
         rng = np.random.default_rng(seed)
         T = np.float32 if seed % 2 == 0 else np.float64
         n = int(rng.choice([3, 20, 100, 485]))
@@ -65,13 +66,14 @@ def render_rounds(seconds, seed, log=print):
         camd = {k: np.asarray(getattr(cam, k)) for k in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w", "lens_radius")}
         g = dict(g0, flat=flat, cam=camd, image=np.zeros((1, 1, 3), T))
         ref, ost = O.render(flat, cam, 64, 36, 6, T=T, max_depth=12, seed=seed, n_chunks=3)
-        for flags in (0, 4, 1, 5):
+        for flags in (0, 4, 1, 5, 8):           # matrix-pipe scan, all-VALU scan, cull, all-VALU cull, ray-pool kernel (Float32; ignored for Float64)
             img, st = gpu_render(g, width=64, height=36, spp=6, n_chunks=3, max_depth=12, seed=seed, flags=flags)
             imgs += 1
             if not (np.array_equal(img, ref, equal_nan=True) and st.segments == ost["segments"]):
                 bad_imgs += 1
                 log(f"IMAGE MISMATCH seed {seed} n {n} scale {scale} flags {flags}: {(img != ref).sum()} channels")
         seed += 1
+        scenes += 1
     return imgs, bad_imgs, seed
 
 
