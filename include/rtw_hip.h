@@ -81,6 +81,17 @@ typedef struct {
  * the image is identical bit for bit.  Measured 14 % SLOWER than the default on MI355X (DESIGN.md section 6.4 says why); kept as
  * an independent cross-check of the default kernel and as the starting point for hardware with more LDS per CU. */
 #define RTW_FLAG_RAY_POOL 8
+/* RTW_FLAG_RCCL_REDUCE (rtw_render_f32/_f64 with a device list): every device renders its tiles into a zero-padded full frame and
+ * ONE ncclReduce(sum, root = the first device of the list) over xGMI assembles the image (BASELINE configs[3]: "tile-sharded + RCCL
+ * framebuffer reduce"; x + 0 == x, so the sum is the image bit for bit).  librccl is loaded on demand (dlopen; RTW_RCCL_LIB overrides
+ * the path), one communicator per device list is kept until rtw_shutdown().  The devices of the list must be distinct.  Default (0):
+ * compact shards gathered with peer copies (1/N of a frame per device instead of a whole one). */
+#define RTW_FLAG_RCCL_REDUCE 16
+/* rtw_stats_t.gather_path (bits): how the shards of the last multi-device render reached the first device */
+#define RTW_GATHER_PEER 1         /* hipMemcpyPeerAsync with peer access enabled in both directions (xGMI)      */
+#define RTW_GATHER_HOST_STAGED 2  /* no peer access on this platform: D2H into pinned memory, H2D on the root   */
+#define RTW_GATHER_RCCL 4         /* ncclReduce (RTW_FLAG_RCCL_REDUCE)                                           */
+#define RTW_GATHER_SAME_DEVICE 8  /* a shard on the root's own device rendered straight into the gather buffer   */
 
 /* Positional arguments of render() plus the keyword extras of the shim. */
 typedef struct {
@@ -97,8 +108,8 @@ typedef struct {
     int32_t device;       /* HIP device ordinal; -1 = current device                          */
     int32_t gamma;        /* 1 = sqrt per channel (rgb_gamma2, src/vec.jl:22); 0 = linear mean */
     int32_t flags;        /* 0, or RTW_FLAG_* (opt-in modes; the image is identical in every mode)    */
-    int32_t n_devices;    /* rtw_render_f32/_f64 only (Julia keyword `devices`): 0 or 1 = the one device
-                             named by `device`; N > 1 = the N ordinals in device_ids; -1 = every visible
+    int32_t n_devices;    /* rtw_render_f32/_f64 only (Julia keyword `devices`): 0 (or 1 with device_ids null) = the one
+                             device named by `device`; N >= 1 = the N ordinals in device_ids; -1 = every visible
                              device.  The 8x8 tiles are dealt round-robin to the devices (a stream each); the
                              shards are gathered in HBM of the first device of the list (peer copies over xGMI)
                              and the frame is copied to `out` once.  The image is identical for every device list. */
@@ -119,7 +130,7 @@ typedef struct {
     int32_t n_chunks;       /* chunks per pixel actually used                                 */
     int32_t grid_blocks;    /* trace kernel launch geometry                                   */
     int32_t block_threads;
-    int32_t reserved;
+    int32_t gather_path;    /* multi-device renders: RTW_GATHER_* bits; 0 otherwise                  */
 } rtw_stats_t;
 
 int rtw_abi_version(void);

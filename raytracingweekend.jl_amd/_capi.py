@@ -43,7 +43,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("n_chunks", C.c_int32),
-                ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("reserved", C.c_int32)]
+                ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("gather_path", C.c_int32)]
 
 
 _lib = None
@@ -121,6 +121,8 @@ FLAG_GROUP_CULL = 1      # include/rtw_hip.h RTW_FLAG_GROUP_CULL
 FLAG_COMPACT_TILES = 2   # include/rtw_hip.h RTW_FLAG_COMPACT_TILES
 FLAG_SCAN_VALU = 4       # include/rtw_hip.h RTW_FLAG_SCAN_VALU
 FLAG_RAY_POOL = 8        # include/rtw_hip.h RTW_FLAG_RAY_POOL
+FLAG_RCCL_REDUCE = 16    # include/rtw_hip.h RTW_FLAG_RCCL_REDUCE
+GATHER_PEER, GATHER_HOST_STAGED, GATHER_RCCL, GATHER_SAME_DEVICE = 1, 2, 4, 8    # rtw_stats_t.gather_path bits
 ABI_VERSION = 2
 
 
@@ -143,7 +145,6 @@ def make_params(width, height, spp, max_depth=16, seed=1, n_chunks=0, shard_inde
         P._keep_ids = ids                     # keep the array alive as long as the struct
         if len(devices) == 1:
             P.device = int(devices[0])
-        else:
-            P.n_devices = len(devices)
-            P.device_ids = C.cast(ids, C.POINTER(C.c_int32))
+        P.n_devices = len(devices)            # (a list of one: the same device, named both ways)
+        P.device_ids = C.cast(ids, C.POINTER(C.c_int32))
     return P

@@ -9,8 +9,11 @@
 #include "../../include/rtw_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl is loaded on demand (dlopen), never linked
+#include <dlfcn.h>
 
 #include <algorithm>
+#include <map>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -94,6 +97,8 @@ struct HostCtx {
     void *d_img = nullptr;  size_t d_cap = 0;      // device image / compact shard
     void *d_aux = nullptr;  size_t aux_cap = 0;    // multi-device root: the gathered compact shards
     hipEvent_t done_ev = nullptr;                  // multi-device: this shard has arrived in the root's gather buffer
+    void *h_stage = nullptr; size_t stage_cap = 0; // multi-device without peer access: pinned staging of this shard
+    unsigned long long last_use = 0;               // pool eviction: least recently used idle entry
     ~HostCtx();
 };
 
@@ -103,6 +108,8 @@ struct DeviceCtx {
     std::mutex mu;
     std::vector<std::unique_ptr<RenderRec>> recs;
     std::vector<std::unique_ptr<HostCtx>> host;    // at most RTW_HOST_CTX_POOL cached entries
+    std::map<int, bool> peer;                      // peer device -> access enabled in both directions (ensure_peer)
+    unsigned long long use_clock = 0;
 };
 #define RTW_HOST_CTX_POOL 8
 using CtxPtr = std::shared_ptr<DeviceCtx>;       // holders keep a context alive across a concurrent rtw_shutdown()
@@ -582,7 +589,7 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
-    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_RAY_POOL)) return fail(-2, "unknown flags 0x%x", p->flags);
+    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_RAY_POOL | RTW_FLAG_RCCL_REDUCE)) return fail(-2, "unknown flags 0x%x", p->flags);
     // default rule: about 4 samples per chunk, between 16 and 256 chunks (never more than spp):
     // enough items for load balance, few enough stream set-ups (1 sample per chunk costs 7 % at Float64)
     int nch = p->n_chunks > 0 ? p->n_chunks : std::min(p->spp, std::max(16, std::min(256, p->spp / 4)));
@@ -691,7 +698,8 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     // (Slots per workgroup: 24 / 12 / 4 -- one-pixel jobs need many slots in flight; with 6 they ran 33 % slower.)
     int job_shift = nch >= 16 ? 2 : 4;
     if (nch >= 64 && n_local * 16 < 150 * grid) job_shift = 0;
-    static const int env_job_pixels = getenv("RTW_JOB_PIXELS") ? atoi(getenv("RTW_JOB_PIXELS")) : 0;      // measurement aid (tools/gpu_jobshape.sh)
+    // (measurement aid for A/B runs, tools/gpu_ab.sh: RTW_JOB_PIXELS = 1, 4, 8 or 16; any other value is ignored)
+    static const int env_job_pixels = [] { const char *e = getenv("RTW_JOB_PIXELS"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 4 || v == 8 || v == 16) ? v : 0; }();
     const int job_pixels = p->job_pixels ? p->job_pixels : env_job_pixels;
     if (job_pixels == 16 || job_pixels == 8 || job_pixels == 4 || job_pixels == 1) {
         job_shift = job_pixels == 16 ? 4 : job_pixels == 8 ? 3 : job_pixels == 4 ? 2 : 0;
@@ -805,12 +813,104 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     return rc;
 }
 
+
+// ---- multi-device plumbing ---------------------------------------------------------------------------------------
+// Peer access between a shard's device and the gather root, enabled once per pair in both directions.  hipMemcpyPeerAsync works
+// without it too (the runtime then stages through host memory by itself), but "peer copies over xGMI" is only true when the access is
+// enabled -- so it is asked for explicitly, and when the platform says no the shard takes the DOCUMENTED fallback: D2H into its own
+// pinned staging buffer, H2D on the root's stream (gather_path bit RTW_GATHER_HOST_STAGED in rtw_stats_t).
+// Test aids (one-GPU boxes): RTW_DEBUG_REMOTE_SHARDS=1 treats every shard but the first as if it were on another device (own image
+// buffer + copy into the gather buffer), RTW_DEBUG_NO_PEER=1 forces the host-staged fallback.
+int ensure_peer(const CtxPtr &ctx, int dev, int root, bool *direct) {
+    *direct = false;
+    static const bool no_peer = getenv("RTW_DEBUG_NO_PEER") != nullptr && atoi(getenv("RTW_DEBUG_NO_PEER")) != 0;
+    if (no_peer) return 0;
+    if (dev == root) { *direct = true; return 0; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->peer.find(root);
+    if (it != ctx->peer.end()) { *direct = it->second; return 0; }
+    int can_fwd = 0, can_back = 0;
+    bool ok = hipDeviceCanAccessPeer(&can_fwd, dev, root) == hipSuccess && hipDeviceCanAccessPeer(&can_back, root, dev) == hipSuccess && can_fwd && can_back;
+    if (ok) {
+        const int pair[2][2] = {{dev, root}, {root, dev}};
+        for (auto &pr : pair) {
+            hipError_t e = hipSetDevice(pr[0]);
+            if (e == hipSuccess) e = hipDeviceEnablePeerAccess(pr[1], 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+            if (e != hipSuccess) { (void)hipGetLastError(); ok = false; }
+        }
+    } else {
+        (void)hipGetLastError();
+    }
+    ctx->peer[root] = ok;
+    *direct = ok;
+    return 0;
+}
+
+// RCCL, loaded on demand (librccl.so is 570 MB: a caller that renders on one device never pays for it).  RTW_RCCL_LIB overrides the path.
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+std::mutex g_rccl_mu;
+RcclApi g_rccl;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_rccl_comms;      // device list -> one communicator per device (ncclCommInitAll)
+
+int rccl_load() {       // g_rccl_mu held
+    if (g_rccl.handle) return 0;
+    const char *env = getenv("RTW_RCCL_LIB");
+    const char *names[] = {env, "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+    void *h = nullptr;
+    for (const char *nm : names) { if (nm && *nm && (h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break; }
+    if (!h) return fail(-30, "RTW_FLAG_RCCL_REDUCE: cannot load librccl (%s)", dlerror());
+    RcclApi a;
+    a.handle = h;
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(h, "ncclCommInitAll");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.Reduce = (decltype(a.Reduce))dlsym(h, "ncclReduce");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.CommInitAll || !a.CommDestroy || !a.Reduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString) { dlclose(h); return fail(-30, "librccl lacks a symbol this library needs"); }
+    g_rccl = a;
+    return 0;
+}
+#define NCCL_TRY(expr)                                                                        \
+    do {                                                                                      \
+        ncclResult_t _r = (expr);                                                             \
+        if (_r != ncclSuccess) return fail(1000 + (int)_r, "%s: %s", #expr, g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+// the communicators of a device list (created once, kept until rtw_shutdown)
+int rccl_comms(const std::vector<int> &devs, std::vector<ncclComm_t> *out) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (int rc = rccl_load()) return rc;
+    auto it = g_rccl_comms.find(devs);
+    if (it == g_rccl_comms.end()) {
+        std::vector<int> sorted(devs);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            return fail(-2, "RTW_FLAG_RCCL_REDUCE needs distinct devices (a communicator has one rank per GPU)");
+        std::vector<ncclComm_t> comms(devs.size());
+        NCCL_TRY(g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+        it = g_rccl_comms.emplace(devs, std::move(comms)).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
 // ---- host-buffer path --------------------------------------------------------------------------------------------
 HostCtx::~HostCtx() {
     if (device >= 0) HIP_IGNORE(hipSetDevice(device));
     if (scene) rtw_scene_free(scene);
     if (d_img) HIP_IGNORE(hipFree(d_img));
     if (d_aux) HIP_IGNORE(hipFree(d_aux));
+    if (h_stage) HIP_IGNORE(hipHostFree(h_stage));
     if (done_ev) HIP_IGNORE(hipEventDestroy(done_ev));
     if (stream) HIP_IGNORE(hipStreamDestroy(stream));
 }
@@ -852,13 +952,16 @@ int acquire_host(int device, const std::vector<unsigned char> &key, HostLease *o
         std::lock_guard<std::mutex> lk(ctx->mu);
         HostCtx *pick = nullptr;
         for (auto &h : ctx->host) if (!h->busy && h->scene_key == key) { pick = h.get(); break; }     // same scene: nothing to upload
-        if (!pick) for (auto &h : ctx->host) if (!h->busy) { pick = h.get(); break; }
         if (!pick && ctx->host.size() < RTW_HOST_CTX_POOL) {
+            // a scene this device has not seen (or whose entries are all busy): a NEW entry while the pool has room -- a caller that
+            // alternates between two scenes keeps both uploaded
             ctx->host.emplace_back(new HostCtx());
             pick = ctx->host.back().get();
             pick->device = dev;
         }
-        if (pick) { pick->busy = true; out->hc = pick; out->pooled = true; }
+        if (!pick)                                                                                  // pool full: the least recently used idle entry
+            for (auto &h : ctx->host) if (!h->busy && (!pick || h->last_use < pick->last_use)) pick = h.get();
+        if (pick) { pick->busy = true; pick->last_use = ++ctx->use_clock; out->hc = pick; out->pooled = true; }
     }
     if (!out->hc) { out->hc = new HostCtx(); out->hc->device = dev; out->pooled = false; }
     HostCtx *hc = out->hc;
@@ -927,7 +1030,7 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
             return fail(e != hipSuccess ? (int)e : -21, "no HIP device available (%s); librtw_hip has no CPU fallback",
                         e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
         for (int d = 0; d < n; ++d) devs.push_back(d);
-    } else if (p->n_devices > 1) {
+    } else if (p->n_devices > 1 || (p->n_devices == 1 && p->device_ids)) {
         if (!p->device_ids) return fail(-1, "n_devices = %d but device_ids is null", p->n_devices);
         devs.assign(p->device_ids, p->device_ids + p->n_devices);
     } else if (p->n_devices < -1) {
@@ -937,14 +1040,15 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
     std::vector<unsigned char> key;
     scene_key_of(scene, sizeof(T) == 8, key);
 
-    if (devs.size() <= 1) {
-        // ---- one device: render into the cached device image, chunked D2H ----
+    if (devs.size() <= 1 && !((p->flags & RTW_FLAG_RCCL_REDUCE) && devs.size() == 1)) {
+        // ---- one device: render into the cached device image, one D2H ----
         HostLease L;
         if (int rc = acquire_host(devs.size() == 1 ? devs[0] : p->device, key, &L)) return rc;
         HostCtx *hc = L.hc;
         if (int rc = ensure_scene<T>(hc, scene, key)) return rc;
         rtw_params q = *p;
         q.device = hc->device; q.n_devices = 0; q.device_ids = nullptr;
+        q.flags &= ~RTW_FLAG_RCCL_REDUCE;              // (one device: nothing to reduce)
         const bool compact = (q.flags & RTW_FLAG_COMPACT_TILES) != 0;
         const size_t elems = compact ? (size_t)local_tiles(&q) * 64 * 3 : (size_t)q.width * (size_t)q.height * 3;
         if (elems == 0) { g_last.resolved = true; return 0; }
@@ -960,16 +1064,34 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
         return rc;
     }
 
-    // ---- several devices: shard r renders tiles t = r (mod N) compact on its own device and stream; the shards are gathered in
-    //      HBM of the first device (peer copies over xGMI; a shard on the root device renders straight into the gather buffer),
-    //      un-tiled there by one small kernel and the frame crosses PCIe once ----
+    // ---- several devices: shard r renders tiles t = r (mod N) on its own device and stream, then ONE of
+    //   (default)             compact tile-major shards gathered in HBM of the first device -- peer copies over xGMI with peer access
+    //                         enabled per pair (ensure_peer; host-staged fallback when the platform refuses it); a shard on the root
+    //                         device renders straight into the gather buffer --, un-tiled there by one small kernel;
+    //   RTW_FLAG_RCCL_REDUCE  zero-padded full frames summed onto the first device by ONE ncclReduce over xGMI (BASELINE configs[3]'s
+    //                         "RCCL reduce of per-tile framebuffers": x + 0 == x, so the sum is the image bit for bit);
+    //      and the frame crosses PCIe once ----
     if (p->shard_count != 1) return fail(-2, "n_devices > 1 cannot be combined with shard_index/shard_count");
     if (p->flags & RTW_FLAG_COMPACT_TILES) return fail(-2, "n_devices > 1 writes the full frame (RTW_FLAG_COMPACT_TILES is a per-shard layout)");
     const int N = (int)devs.size();
+    const bool use_rccl = (p->flags & RTW_FLAG_RCCL_REDUCE) != 0;
+    static const bool dbg_remote = getenv("RTW_DEBUG_REMOTE_SHARDS") != nullptr && atoi(getenv("RTW_DEBUG_REMOTE_SHARDS")) != 0;
+    std::vector<ncclComm_t> comms;
+    if (use_rccl) { if (int rc = rccl_comms(devs, &comms)) return rc; }
     std::vector<HostLease> L(N);
-    for (int r = 0; r < N; ++r) {
+    for (int r = 0; r < N; ++r)
         if (int rc = acquire_host(devs[r], key, &L[r])) return fail(rc, "device %d (shard %d of %d): %s", devs[r], r, N, std::string(g_err).c_str());
-        if (int rc = ensure_scene<T>(L[r].hc, scene, key)) return fail(rc, "device %d (shard %d of %d): %s", devs[r], r, N, std::string(g_err).c_str());
+    {   // scene uploads of the devices that do not have it yet, in parallel (a cache miss on 8 devices is 8 x (kd split + a dozen copies))
+        std::vector<int> up_rc(N, 0);
+        std::vector<std::string> up_err(N);
+        std::vector<std::thread> th;
+        for (int r = 0; r < N; ++r) {
+            if (L[r].hc->scene && L[r].hc->scene_key == key) continue;
+            th.emplace_back([&, r] { up_rc[r] = ensure_scene<T>(L[r].hc, scene, key); if (up_rc[r]) up_err[r] = g_err; });
+        }
+        for (auto &t : th) t.join();
+        for (int r = 0; r < N; ++r)
+            if (up_rc[r]) return fail(up_rc[r], "device %d (shard %d of %d): %s", devs[r], r, N, up_err[r].c_str());
     }
     HostCtx *root = L[0].hc;
     rtw_params q0 = *p;
@@ -977,34 +1099,79 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
     const long pad_tiles = local_tiles(&q0);                               // shard 0 owns the most tiles
     const size_t shard_bytes = (size_t)pad_tiles * 192 * sizeof(T), frame_bytes = (size_t)p->width * p->height * 3 * sizeof(T);
     HIP_TRY(hipSetDevice(root->device));
-    if (int rc = ensure_dev(&root->d_aux, &root->aux_cap, shard_bytes * N)) return rc;
+    if (!use_rccl) { if (int rc = ensure_dev(&root->d_aux, &root->aux_cap, shard_bytes * N)) return rc; }
     if (int rc = ensure_dev(&root->d_img, &root->d_cap, frame_bytes)) return rc;
     std::vector<RenderRec *> recs(N, nullptr);
     std::vector<CtxPtr> rctx(N);
-    int rc = 0;
+    int rc = 0, gather_path = 0;
     for (int r = 0; r < N && !rc; ++r) {
         HostCtx *hc = L[r].hc;
         rtw_params q = *p;
         q.device = hc->device; q.shard_index = r; q.shard_count = N; q.n_devices = 0; q.device_ids = nullptr;
+        q.flags &= ~RTW_FLAG_RCCL_REDUCE;
+        const hipError_t e0 = hipSetDevice(hc->device);
+        if (e0 != hipSuccess) { rc = fail((int)e0, "hipSetDevice(%d): %s", hc->device, hipGetErrorString(e0)); break; }
+        if (use_rccl) {
+            // this shard's tiles in the full-frame layout, zero elsewhere (launch_render clears the frame of a sharded render first)
+            if ((rc = ensure_dev(&hc->d_img, &hc->d_cap, frame_bytes))) break;
+            rc = launch_render<T>(hc->scene, cam, &q, hc->d_img, hc->stream, &recs[r], &rctx[r]);
+            continue;
+        }
         q.flags |= RTW_FLAG_COMPACT_TILES;
         const size_t my_bytes = (size_t)local_tiles(&q) * 192 * sizeof(T);
         char *slot = (char *)root->d_aux + (size_t)r * shard_bytes;
         if (my_bytes == 0) continue;
+        const bool remote = hc->device != root->device || (dbg_remote && hc != root);
         void *d_out = slot;
-        if (hc->device != root->device) {
-            const hipError_t e0 = hipSetDevice(hc->device);               // (the shard buffer belongs to ITS device)
-            if (e0 != hipSuccess) { rc = fail((int)e0, "hipSetDevice(%d): %s", hc->device, hipGetErrorString(e0)); break; }
-            if ((rc = ensure_dev(&hc->d_img, &hc->d_cap, my_bytes))) break;
+        if (remote) {
+            if ((rc = ensure_dev(&hc->d_img, &hc->d_cap, my_bytes))) break;        // (the shard buffer belongs to ITS device)
             d_out = hc->d_img;
         }
         if ((rc = launch_render<T>(hc->scene, cam, &q, d_out, hc->stream, &recs[r], &rctx[r]))) break;
         hipError_t e = hipSuccess;
-        if (hc->device != root->device) e = hipMemcpyPeerAsync(slot, root->device, d_out, hc->device, my_bytes, hc->stream);
+        bool staged = false;
+        if (remote) {
+            bool direct = false;
+            if ((rc = ensure_peer(L[r].ctx, hc->device, root->device, &direct))) break;
+            if (direct) {
+                gather_path |= RTW_GATHER_PEER;
+                e = hipSetDevice(hc->device);
+                if (e == hipSuccess) e = hipMemcpyPeerAsync(slot, root->device, d_out, hc->device, my_bytes, hc->stream);
+            } else {
+                // the documented fallback: through this shard's pinned staging buffer
+                gather_path |= RTW_GATHER_HOST_STAGED;
+                staged = true;
+                if (hc->stage_cap < my_bytes) {
+                    if (hc->h_stage) { HIP_IGNORE(hipHostFree(hc->h_stage)); hc->h_stage = nullptr; hc->stage_cap = 0; }
+                    e = hipHostMalloc(&hc->h_stage, my_bytes, hipHostMallocDefault);
+                    if (e == hipSuccess) hc->stage_cap = my_bytes;
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(hc->h_stage, d_out, my_bytes, hipMemcpyDeviceToHost, hc->stream);
+            }
+        } else if (hc != root) {
+            gather_path |= RTW_GATHER_SAME_DEVICE;
+        }
         if (e == hipSuccess) e = hipEventRecord(hc->done_ev, hc->stream);
-        if (e == hipSuccess && hc != root) { e = hipSetDevice(root->device); if (e == hipSuccess) e = hipStreamWaitEvent(root->stream, hc->done_ev, 0); }
+        if (e == hipSuccess && hc != root) {
+            e = hipSetDevice(root->device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(root->stream, hc->done_ev, 0);
+            if (e == hipSuccess && staged) e = hipMemcpyAsync(slot, hc->h_stage, my_bytes, hipMemcpyHostToDevice, root->stream);
+        }
         if (e != hipSuccess) rc = fail((int)e, "device %d (shard %d of %d): gather failed: %s", hc->device, r, N, hipGetErrorString(e));
     }
-    if (!rc) {
+    if (!rc && use_rccl) {
+        gather_path |= RTW_GATHER_RCCL;
+        const ncclDataType_t dt = sizeof(T) == 8 ? ncclFloat64 : ncclFloat32;
+        const size_t count = (size_t)p->width * p->height * 3;
+        ncclResult_t nr = g_rccl.GroupStart();
+        for (int r = 0; r < N && nr == ncclSuccess; ++r)
+            nr = g_rccl.Reduce(L[r].hc->d_img, root->d_img, count, dt, ncclSum, 0, comms[r], L[r].hc->stream);
+        const ncclResult_t ne = g_rccl.GroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) rc = fail(1000 + (int)nr, "ncclReduce over %d devices: %s", N, g_rccl.GetErrorString(nr));
+        if (!rc) { const hipError_t e = hipSetDevice(root->device); if (e != hipSuccess) rc = fail((int)e, "hipSetDevice: %s", hipGetErrorString(e)); }
+        if (!rc) rc = copy_out(root, root->d_img, out, frame_bytes);
+    } else if (!rc) {
         hipError_t e = hipSetDevice(root->device);
         const long n_tiles = (long)((p->height + 7) / 8) * ((p->width + 7) / 8);
         if (e == hipSuccess && n_tiles > 0) {
@@ -1027,8 +1194,9 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
         release_rec(rctx[r], recs[r], rc == 0);
         a.samples += st.samples; a.segments += st.segments; a.sphere_tests += st.sphere_tests;
         a.kernel_ms = std::max(a.kernel_ms, st.kernel_ms); a.total_ms = std::max(a.total_ms, st.total_ms);
-        a.n_chunks = st.n_chunks; a.grid_blocks = std::max(a.grid_blocks, st.grid_blocks); a.block_threads = 256;
+        a.n_chunks = st.n_chunks; a.grid_blocks = std::max(a.grid_blocks, st.grid_blocks); a.block_threads = std::max(a.block_threads, st.block_threads);
     }
+    a.gather_path = gather_path;
     g_last.resolved = rc == 0;
     return rc;
 }
@@ -1169,11 +1337,19 @@ int rtw_shutdown(void) {
     for (auto &c : g_ctx) {
         HIP_IGNORE(hipSetDevice(c->device));
         std::lock_guard<std::mutex> lk2(c->mu);
-        c->recs.clear();
-        // (host contexts in use by a render in flight on another thread stay alive with their DeviceCtx: that thread holds a CtxPtr)
+        // Records that some thread still references (`owned`: a host render in flight on another thread, or a thread's last render)
+        // are NOT destroyed here: that thread holds a CtxPtr, the DeviceCtx -- and with it these records -- lives until it lets go.
+        c->recs.erase(std::remove_if(c->recs.begin(), c->recs.end(), [](const std::unique_ptr<RenderRec> &r) { return !r->owned; }), c->recs.end());
+        // (host contexts in use by a render in flight on another thread stay alive with their DeviceCtx in the same way)
         c->host.erase(std::remove_if(c->host.begin(), c->host.end(), [](const std::unique_ptr<HostCtx> &h) { return !h->busy; }), c->host.end());
     }
     g_ctx.clear();
+    {
+        std::lock_guard<std::mutex> lr(g_rccl_mu);
+        for (auto &kv : g_rccl_comms)
+            for (ncclComm_t cm : kv.second) (void)g_rccl.CommDestroy(cm);
+        g_rccl_comms.clear();
+    }
     return 0;
 }
 

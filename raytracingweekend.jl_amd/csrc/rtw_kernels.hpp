@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
     }
     __syncthreads();
 
-    if (lane == 0) sh->t_wave[threadIdx.x >> 6] = wall_clock64();     // (in LDS: not a register pair held across the lane loop)
+    if (lane == 0 && (threadIdx.x >> 6) < 4u) sh->t_wave[threadIdx.x >> 6] = wall_clock64();     // (in LDS: not a register pair held across the lane loop)
     // ---- wave-uniform state ----
     unsigned pool_next = 0, pool_end = 0;   // unassigned items [pool_next, pool_end) of the wave's current batch
     unsigned pool_slot = 0, pool_b = 0;
@@ -650,13 +650,14 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         // finish reports for all four.
         __hip_atomic_fetch_add(&sh->fin_segments, n_segments, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&sh->fin_samples, n_samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_store(&sh->t_wave[4u + (threadIdx.x >> 6)], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__hip_atomic_fetch_add(&sh->fin_waves, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 3u) {      // (256 threads: four waves)
+        if ((threadIdx.x >> 6) < 4u) __hip_atomic_store(&sh->t_wave[4u + (threadIdx.x >> 6)], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned nw = blockDim.x >> 6;                                     // waves of this workgroup (t_wave holds up to four)
+        if (__hip_atomic_fetch_add(&sh->fin_waves, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == nw - 1u) {
             atomicAdd(&ctr->segments, __hip_atomic_load(&sh->fin_segments, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             atomicAdd(&ctr->samples, __hip_atomic_load(&sh->fin_samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             // the end-of-queue drain: first wave start, last wave end, sum of the wave ends, waves by end time
             unsigned long long t_start = ~0ull, t_end = 0ull, t_sum = 0ull;
-            for (unsigned w = 0; w < 4u; ++w) {
+            for (unsigned w = 0; w < nw && w < 4u; ++w) {
                 const unsigned long long a = __hip_atomic_load(&sh->t_wave[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const unsigned long long e = __hip_atomic_load(&sh->t_wave[4u + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 t_start = a < t_start ? a : t_start; t_end = e > t_end ? e : t_end; t_sum += e;
@@ -664,9 +665,9 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             const unsigned long long t0_seen = atomicMin(&ctr->t_first, t_start);
             atomicMax(&ctr->t_last, t_end);
             atomicAdd(&ctr->t_end_sum, t_sum);
-            atomicAdd(&ctr->n_waves, 4ull);
+            atomicAdd(&ctr->n_waves, (unsigned long long)nw);
             const unsigned long long t0 = t0_seen < t_start ? t0_seen : t_start;
-            for (unsigned w = 0; w < 4u; ++w) {
+            for (unsigned w = 0; w < nw && w < 4u; ++w) {
                 const unsigned long long bin = (__hip_atomic_load(&sh->t_wave[4u + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - t0) / 25000ull;
                 atomicAdd(&ctr->end_hist[bin < 4095ull ? (unsigned)bin : 4095u], 1u);
             }

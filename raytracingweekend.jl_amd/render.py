@@ -23,14 +23,16 @@ def _as_image(flat, height, width):
 
 
 def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chunks=0, device=-1, gamma=True,
-           group_cull=False, devices=None, scan_valu=False, ray_pool=False):
+           group_cull=False, devices=None, scan_valu=False, ray_pool=False, rccl_reduce=False):
     """Render ``scene`` through ``cam``; returns ``img[i, j, :]`` (row i, column j, RGB) of the
     camera's element type, memory-identical to the reference's ``Matrix{RGB{T}}``.
     ``group_cull=True`` selects the opt-in accelerated scan (same image, include/rtw_hip.h);
     ``scan_valu=True`` the all-VALU plain scan (RTW_FLAG_SCAN_VALU: same image, for A/B measurements);
     ``ray_pool=True`` the ray-pool kernel (RTW_FLAG_RAY_POOL: rays parked in LDS between stages; same image, 14 % slower).
     ``devices``: ``"all"`` or a list of HIP ordinals -- the 8x8 tiles are dealt to those devices
-    inside the library (``rtw_params.n_devices/device_ids``); the image is the same for any list."""
+    inside the library (``rtw_params.n_devices/device_ids``); the image is the same for any list.
+    ``rccl_reduce=True`` (with ``devices``): the shards are put together by ONE ncclReduce of zero-padded frames inside the
+    library (RTW_FLAG_RCCL_REDUCE) instead of peer copies of compact shards; ``last_stats()["gather_path"]`` says which path ran."""
     if not isinstance(cam, Camera):
         raise TypeError("cam must be a Camera")
     T = cam.elem_type
@@ -45,7 +47,7 @@ def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chun
     Cm = _capi.make_camera(cam, T)
     P = _capi.make_params(image_width, height, n_samples, depth, seed, n_chunks, 0, 1, device, 1 if gamma else 0,
                            (_capi.FLAG_GROUP_CULL if group_cull else 0) | (_capi.FLAG_SCAN_VALU if scan_valu else 0) |
-                           (_capi.FLAG_RAY_POOL if ray_pool else 0), devices=devices)
+                           (_capi.FLAG_RAY_POOL if ray_pool else 0) | (_capi.FLAG_RCCL_REDUCE if rccl_reduce else 0), devices=devices)
     out = np.empty(height * int(image_width) * 3, dtype=T)
     fn = L.rtw_render_f64 if _capi.is_f64(T) else L.rtw_render_f32
     _capi.check(fn(C.byref(S), C.byref(Cm), C.byref(P), out.ctypes.data_as(C.c_void_p)))

@@ -169,3 +169,91 @@ def test_f64_published_configuration_modes_identical(rtw):
     assert sa["segments"] == sb["segments"] == sc["segments"]
     assert bool(torch.equal(a, b)) and bool(torch.equal(a, c))
     dr.close()
+
+
+# ---- several devices behind the C ABI -----------------------------------------------------------------------------------------
+_PROBE = r"""
+import hashlib, json, sys
+import numpy as np
+import torch
+torch.cuda.init()
+import rtw_amd as R
+T = np.float32
+R.reseed()
+scene = R.scene_random_spheres(elem_type=T)
+cam = R.t_cam1(elem_type=T)
+spec = json.loads(sys.argv[1])
+out = {}
+for name, kw in spec.items():
+    img = R.render(scene, cam, 200, 12, depth=16, seed=5, **kw)
+    st = R.last_stats()
+    out[name] = {"sha": hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest(), "gather_path": st["gather_path"], "segments": st["segments"]}
+print(json.dumps(out))
+"""
+
+
+def _probe(spec, env_extra=None):
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, "-c", _PROBE, json.dumps(spec)], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_gather_branches_on_one_device():
+    """The branches of the in-library multi-device gather that a one-GPU box cannot reach by itself, forced by the test aids of
+    rtw_hip.hip: RTW_DEBUG_REMOTE_SHARDS=1 makes every shard but the first render into its own buffer and COPY it into the gather
+    buffer (hipMemcpyPeerAsync, the cross-device branch); with RTW_DEBUG_NO_PEER=1 the copy takes the host-staged fallback (pinned
+    staging, D2H + H2D) that a platform without peer access gets.  Same frame as one device, and rtw_stats_t.gather_path says which ran."""
+    one = _probe({"one": {}})["one"]
+    same = _probe({"x": {"devices": [0, 0, 0]}})["x"]
+    assert same["sha"] == one["sha"] and same["gather_path"] == 8 and same["segments"] == one["segments"]          # RTW_GATHER_SAME_DEVICE
+    peer = _probe({"x": {"devices": [0, 0, 0]}}, {"RTW_DEBUG_REMOTE_SHARDS": "1"})["x"]
+    assert peer["sha"] == one["sha"] and peer["gather_path"] == 1                                                # RTW_GATHER_PEER
+    staged = _probe({"x": {"devices": [0, 0, 0, 0, 0]}}, {"RTW_DEBUG_REMOTE_SHARDS": "1", "RTW_DEBUG_NO_PEER": "1"})["x"]
+    assert staged["sha"] == one["sha"] and staged["gather_path"] == 2                                            # RTW_GATHER_HOST_STAGED
+
+
+def test_in_library_rccl_reduce_one_rank():
+    """RTW_FLAG_RCCL_REDUCE with a device list of one: librccl is loaded on demand, ncclCommInitAll + ncclReduce run behind the C
+    ABI (no torch.distributed), the frame is the one-device frame.  (A communicator cannot hold the same GPU twice, so more than
+    one rank needs more than one GPU: test_multi_gpu_* below.)"""
+    r = _probe({"one": {}, "rccl": {"devices": [0], "rccl_reduce": True}})
+    assert r["rccl"]["sha"] == r["one"]["sha"] and r["rccl"]["gather_path"] == 4 and r["rccl"]["segments"] == r["one"]["segments"]
+    from rtw_amd._capi import RtwError
+    import rtw_amd as R
+    with pytest.raises(RtwError, match="distinct devices"):
+        R.render(R.scene_2_spheres(elem_type=np.float32), R.t_default_cam(), 96, 1, devices=[0, 0], rccl_reduce=True)
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 MI355X (the driver's multi-GPU tier); one-GPU boxes cover the same code through the test aids above")
+def test_multi_gpu_in_library_paths_match_one_device():
+    """N physical devices behind the C ABI: compact shards gathered with peer copies (peer access must be ON: gather_path ==
+    RTW_GATHER_PEER) and the RCCL reduce of zero-padded frames -- both the one-device frame, bit for bit."""
+    n = _n_gpus()
+    r = _probe({"one": {}, "peer": {"devices": list(range(n))}, "all": {"devices": "all"}, "rccl": {"devices": list(range(n)), "rccl_reduce": True}})
+    assert r["peer"]["sha"] == r["one"]["sha"] == r["all"]["sha"] == r["rccl"]["sha"]
+    assert r["peer"]["gather_path"] in (1, 2), r["peer"]             # peer copies (or the documented fallback where the platform refuses peer access)
+    assert r["rccl"]["gather_path"] == 4
+    assert r["peer"]["segments"] == r["one"]["segments"] == r["rccl"]["segments"]
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 MI355X: bench.py --gpus 2 over the real nccl (RCCL) backend")
+@pytest.mark.parametrize("collective", ["reduce", "gather"])
+def test_multi_gpu_bench_rccl_matches_one_rank(collective):
+    from test_gpu_round3 import SMALL, _bench
+    p1, one = _bench(["--gpus", "1"] + SMALL)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    p2, two = _bench(["--gpus", "2", "--collective", collective] + SMALL)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    assert two["backend"] == "nccl" and two["world_size_observed"] == 2 and two["one_device_emulation"] is False
+    assert two["frame_sha256"] == one["frame_sha256"]
+    assert two["collective_ms"] > 0 and two["render_ms_max"] >= two["render_ms_min"] > 0
+    assert sorted(r["device"] for r in two["per_rank"]) == [0, 1]
