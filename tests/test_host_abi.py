@@ -46,10 +46,10 @@ def test_flag_constants_match_header(rtw):
     header = open(os.path.join(ROOT, "include", "rtw_hip.h")).read()
     flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+RTW_FLAG_([A-Z_]+)\s+(\d+)", header)}
     assert flags == {"GROUP_CULL": _capi.FLAG_GROUP_CULL, "COMPACT_TILES": _capi.FLAG_COMPACT_TILES, "SCAN_VALU": _capi.FLAG_SCAN_VALU,
-                     "RAY_POOL": _capi.FLAG_RAY_POOL}
-    assert sorted(flags.values()) == [1, 2, 4, 8]
+                     "RAY_POOL": _capi.FLAG_RAY_POOL, "RCCL_REDUCE": _capi.FLAG_RCCL_REDUCE}
+    assert sorted(flags.values()) == [1, 2, 4, 8, 16]
     jl = open(os.path.join(ROOT, "julia", "RTWeekendHIP.jl")).read()
-    assert "(group_cull ? 1 : 0) | (scan_valu ? 4 : 0) | (ray_pool ? 8 : 0)" in jl
+    assert "(group_cull ? 1 : 0) | (scan_valu ? 4 : 0) | (ray_pool ? 8 : 0) | (rccl_reduce ? 16 : 0)" in jl
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
