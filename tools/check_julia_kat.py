@@ -119,6 +119,20 @@ def predicted_lines(outdir):
                 head = " ".join(fmt(x, T) for x in (*o, *d, *c, T(r)))
                 tail = "miss" if h is None else " ".join(fmt(x, T) for x in (h["t"], *h["p"], *h["n"])) + " " + ("1" if h["front"] else "0")
                 out.append(f"hit {name} {ri} {si}: {head} -> {tail}")
+        # the tmin self-intersection regime on the ground sphere (julia_kat.jl, 4b)
+        gc, gr = np.array([0, -1000, -1], T), T(1000)
+        us = [np.array(u, T) for u in ((0.6, 0.1, -0.7), (-0.3, -0.9, 0.2), (0, -0.999, 0.02), (0.5, 0.5, 0.5))]
+        for k in range(16):
+            d = normalize(np.array([T(-13) + T(0.37) * T(k), T(-2.2) - T(0.03) * T(k), T(-3.1) + T(0.21) * T(k)], T))
+            h = O.hit_sphere(gc, gr, np.array([13, 2, 3], T), d, T(1e-4), np.inf, T)
+            if h is None:
+                out.append(f"selfhit {name} {k}: primary miss"); continue
+            outs = []
+            for u in us:
+                n = np.asarray(h["n"], T)
+                h2 = O.hit_sphere(gc, gr, np.asarray(h["p"], T), normalize(np.array([n[0] + u[0], n[1] + u[1], n[2] + u[2]], T)), T(1e-4), np.inf, T)
+                outs.append("miss" if h2 is None else fmt(h2["t"], T))
+            out.append(f"selfhit {name} {k}: " + " ".join(fmt(x, T) for x in (h["t"], *h["p"])) + " -> " + " ".join(outs))
         img, _ = O.render(R.flatten_scene(R.scene_2_spheres(elem_type=T), T), R.t_default_cam(elem_type=T), 96, 54, 16, T=T, max_depth=16,
                           rng_mode=O.REF_SERIAL, ref_threads=1, product_order=O.PRODUCT_REFERENCE)
         np.ascontiguousarray(img.transpose(1, 0, 2)).astype(T).tofile(os.path.join(outdir, f"julia_render_2spheres_96x54_16spp_{name}.bin"))
@@ -166,6 +180,7 @@ def check(path):
         item(f"StaticArrays normalize/dot {name}", [f"normalize {name}", f"dot {name}"], "inv(norm(v)) * v; (x1y1 + x2y2) + x3y3", T)
         item(f"tand {name}", [f"tand {name}"], "src/camera.jl:23", T)
         item(f"hit(::Sphere) {name} (@fastmath contraction of the discriminant)", [f"hit {name}"], "src/hit.jl:12-35", T)
+        item(f"tmin self-intersection on the r = 1000 ground sphere {name}", [f"selfhit {name}"], "src/ray_color.jl:19, src/hit.jl:19-29", T)
     # a failing seed expansion: say WHICH expansion Julia uses (two are plausible; the package source is not in the reference tree)
     for seed in (1, 2):
         k = f"rng_state seed={seed}"

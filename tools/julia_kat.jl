@@ -11,6 +11,9 @@
 #   2. scene_random_spheres(elem_type=T) after reseed!()  (SoA dump)
 #   3. default_camera presets (22 scalars)
 #   4. StaticArrays normalize / dot, Base tand, and hit(::Sphere) on fixed rays (@fastmath contraction)
+#   4b. the tmin self-intersection regime on the r = 1000 ground sphere (src/ray_color.jl:19: tmin = T(1e-4) is the size of a binary32
+#       ulp there -- it is what makes Float32 take 3.94 segments per sample against 2.71 in Float64): rays that LEAVE a computed hit
+#       point on the ground sphere, steep to grazing, and whether hit(ground, ...) finds the far root again
 #   5. render(scene_2_spheres, default cam, 96, 16) with ONE thread (the reference's own smoke
 #      render, test/runtests.jl:194) -> compare with the oracle's REF_SERIAL, ref_threads = 1
 using RayTracingWeekend, StaticArrays, RandomNumbers.Xorshifts, Printf
@@ -61,6 +64,19 @@ for T in (Float32, Float64)
         rec = RayTracingWeekend.hit(sp, RayTracingWeekend.Ray(o, d), T(1e-4), typemax(T))
         println("hit $T $ri $si: ", vals((o..., d..., sp.center..., sp.radius)), " -> ",
                 rec === nothing ? "miss" : vals((rec.t, rec.p..., rec.n⃗..., rec.front_face ? 1 : 0)))
+    end
+    ground = Sphere(SA{T}[0, -1000, -1], T(1000), Lambertian(SA{T}[0.5, 0.5, 0.5]))
+    us = (SA{T}[0.6, 0.1, -0.7], SA{T}[-0.3, -0.9, 0.2], SA{T}[0, -0.999, 0.02], SA{T}[0.5, 0.5, 0.5])
+    for k in 0:15
+        d = normalize(SA{T}[-13 + T(0.37) * k, T(-2.2) - T(0.03) * k, T(-3.1) + T(0.21) * k])
+        rec = RayTracingWeekend.hit(ground, RayTracingWeekend.Ray(SA{T}[13, 2, 3], d), T(1e-4), typemax(T))
+        rec === nothing && (println("selfhit $T $k: primary miss"); continue)
+        outs = String[]
+        for u in us
+            rec2 = RayTracingWeekend.hit(ground, RayTracingWeekend.Ray(rec.p, normalize(rec.n⃗ + u)), T(1e-4), typemax(T))
+            push!(outs, rec2 === nothing ? "miss" : fmt(rec2.t))
+        end
+        println("selfhit $T $k: ", vals((rec.t, rec.p...)), " -> ", join(outs, " "))
     end
     Threads.nthreads() == 1 || @warn "run with -t1: the image depends on the thread count (SURVEY F6)"
     img = render(scene_2_spheres(elem_type=T), default_camera(SA{T}[0, 0, 0]), 96, 16)
