@@ -37,6 +37,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   value        -- device-resident rate (scene in HBM, image left in HBM), as the task's bench contract prescribes;
                   `value_end_to_end` is SURVEY 8(d)'s metric: the host-buffer entry point rtw_render_* timed the same way (barrier +
                   synchronize around K calls; render + D2H of the image into the caller's buffer; scene upload cached by the library).
+  ray_pool     -- the same workload with RTW_FLAG_RAY_POOL (the ray-pool kernel, rtw_pool.hpp): same image, slower; reported as measured.
   scan_valu    -- the same workload with RTW_FLAG_SCAN_VALU (the contract discriminant for every
                   sphere on the vector ALUs, the round-1/2 scan): same image, for comparison.
   cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
@@ -96,6 +97,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the accelerated / scan_valu / end_to_end / depth16 / f64_4k legs")
     ap.add_argument("--group-cull", action="store_true", help="time the opt-in accelerated scan instead of the plain one")
     ap.add_argument("--scan-valu", action="store_true", help="time the all-VALU plain scan (RTW_FLAG_SCAN_VALU) instead of the matrix-pipe filter")
+    ap.add_argument("--ray-pool", action="store_true", help="time the opt-in ray-pool kernel (RTW_FLAG_RAY_POOL) instead of the lane-loop kernel")
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per pixel (0 = library default rule)")
     ap.add_argument("--emulate-shard-of", type=int, default=0,
                     help="analysis only: on ONE GPU render shard 0 of N (what each rank of an N-GPU run does)")
@@ -202,12 +204,13 @@ class Workload:
         self.renderer.close()
         self.fb = None
 
-    def timed(self, n_steps, n_warm, *, cull, depth, record=None, valu=False, coll_ms=None):
+    def timed(self, n_steps, n_warm, *, cull, depth, record=None, valu=False, coll_ms=None, pool=None):
         """n_warm untimed + n_steps timed steps bracketed by barrier + synchronize; returns max-over-ranks seconds.
         `coll_ms` (a list): per timed step, the HIP-event time between the end of this rank's render and the end of the collective."""
         c, a = self.c, self.c.args
         torch = c.torch
         evs = []
+        pool = a.ray_pool if pool is None else pool
 
         def step(rec, timed_step):
             def shard(idx, cnt):
@@ -215,7 +218,8 @@ class Workload:
                     idx, cnt = 0, a.emulate_shard_of
                 self.renderer.render_into(self.fb.data_ptr(), self.W, self.spp, depth=depth, seed=1, n_chunks=a.chunks, shard_index=idx,
                                           shard_count=cnt, stream=c.stream.cuda_stream, group_cull=cull,
-                                          compact=a.collective == "gather", scan_valu=valu and not cull, n_elems=self.fb.numel())
+                                          compact=a.collective == "gather", scan_valu=valu and not cull, n_elems=self.fb.numel(),
+                                          ray_pool=pool and not cull and not valu)
                 return self.fb
             hook = None
             if timed_step and coll_ms is not None and c.world > 1:
@@ -251,7 +255,7 @@ class Workload:
 
         def call():
             c.R.render(self.scene, self.cam, self.W, self.spp, depth=depth, seed=1, n_chunks=a.chunks, device=c.local_rank,
-                       group_cull=cull, scan_valu=valu and not cull)
+                       group_cull=cull, scan_valu=valu and not cull, ray_pool=a.ray_pool and not cull and not valu)
             k_ms.append(c.R.last_stats()["kernel_ms"])
         t = time.perf_counter()
         call()                                                  # the first call of a scene builds the library's per-device context
@@ -322,7 +326,7 @@ def roofline_of(wl, k_s, tests_per_launch, seg_per_sample, *, cull, valu, world,
         bound, achieved, peak = "mfma", mfma_tflops, MFMA_F16_PEAK_TFLOPS
     return {
         "bound": bound,
-        "kernel": f"rtw::trace_kernel<{'double' if wl.dtype == 'f64' else 'float'}>",
+        "kernel": f"rtw::{'trace_pool_kernel' if (wl.c.args.ray_pool and matrix and wl.dtype == 'f32') else 'trace_kernel'}<{'double' if wl.dtype == 'f64' else 'float'}>",
         "achieved": None if achieved is None else round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": None if achieved is None else round(achieved / peak, 4),
         "definition": None if not matrix else "achieved = EXECUTED f16 matrix-pipe flops (counted ray-sphere tests x 64: two chained v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays) / "
@@ -429,6 +433,14 @@ def main():
         scan_valu = {"mode": "RTW_FLAG_SCAN_VALU (contract discriminant for every sphere on the vector ALUs; same image bit for bit)",
                      "value": round(samples_per_step / dtv / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtv * 1e3, 3),
                      "frame_sha256_equal": (wl.frame_sha256() == sha) if rank == 0 else None}
+    ray_pool = None
+    if extras and not (args.group_cull or args.scan_valu or args.ray_pool) and args.dtype == "f32":
+        stp_ = []
+        dtp_ = wl.timed(1, 0, cull=False, depth=depth, pool=True, record=stp_)
+        ray_pool = {"mode": "RTW_FLAG_RAY_POOL (rays of a workgroup parked in LDS between the stages scan / shade / path end, every stage on full waves of one kind; "
+                            "same image bit for bit; a measured LOSS on this chip, DESIGN.md section 6.4)",
+                    "value": round(samples_per_step / dtp_ / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtp_ * 1e3, 3),
+                    "block_threads": stp_[0]["block_threads"], "frame_sha256_equal": (wl.frame_sha256() == sha) if rank == 0 else None}
     if extras and depth != 16:
         st16 = []
         dt16 = wl.timed(1, 0, cull=args.group_cull, depth=16, record=st16, valu=args.scan_valu)
@@ -475,7 +487,8 @@ def main():
                                    f"depth {depth}, {wl.jl} ({cfg_name(args.dtype, W, spp, depth, world)})",
                        "scan": "group_cull (opt-in)" if args.group_cull else
                                ("plain linear scan over all spheres, all on the VALU (RTW_FLAG_SCAN_VALU)" if args.scan_valu else
-                                "plain linear scan over all spheres (reference algorithm): matrix-pipe filter + exact test of its candidates"),
+                                "plain linear scan over all spheres (reference algorithm): matrix-pipe filter + exact test of its candidates" +
+                                (", ray-pool kernel (RTW_FLAG_RAY_POOL)" if args.ray_pool else "")),
                        "parallelism": f"tile-sharded x{world}" + (f" + 1 RCCL {args.collective}" if world > 1 else ""),
                        "rng": f"Xoroshiro128+ per (pixel, chunk), {stats[0]['n_chunks']} chunks/pixel; exact fixed-point pixel accumulation"},
             "world_size_observed": dist.get_world_size() if world > 1 else 1, "backend": c.backend,
@@ -485,7 +498,7 @@ def main():
             "per_rank": per_rank, "frame_sha256": sha,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_16t": cpu16,
             "cpu_baseline_all_threads": (legs[-1] if legs else None), "accelerated": accel,
-            "scan_valu": scan_valu, "end_to_end": end_to_end, "depth16": depth16,
+            "scan_valu": scan_valu, "ray_pool": ray_pool, "end_to_end": end_to_end, "depth16": depth16,
         }
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)

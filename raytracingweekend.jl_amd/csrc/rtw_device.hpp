@@ -668,6 +668,9 @@ __device__ __forceinline__ double lane_get(double v, unsigned src_lane) {
 #define RTW_SCAN_GROUP 1
 #endif
 static_assert(RTW_SCAN_GROUP == 1 || RTW_SCAN_GROUP == 2 || RTW_SCAN_GROUP == 4, "groups of 1, 2 or 4 result registers");
+#ifndef RTW_SCAN_CMP
+#define RTW_SCAN_CMP 0       // 1: sign collection by v_cmp -> SGPR lane masks instead of v_alignbit + extraction loop (experiment, rejected)
+#endif
 #ifndef RTW_SCAN_SKIP
 #define RTW_SCAN_SKIP 1      // wave-level early-out per half block (hit_world_mfma): 372.2 vs 376.3 ms.  (Left to the compiler it is
                              // if-converted -- both sides executed -- and gains nothing: the sign collection's side is fenced by an asm.)
@@ -872,6 +875,23 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             t &= __float_as_uint(Wv[15]);
             return !__any((int)t >= 0);
         };
+#if RTW_SCAN_CMP
+        // Experiment: one v_cmp_ge_f32 per result register -> a 64-bit lane mask in SGPRs; a non-empty mask
+        // records its lanes' candidates at once (entry = recording lane << 16 | block << 5 | half << 4 | register), no per-lane mask
+        // word, no extraction loop.  Measured: see DESIGN.md section 6.3.
+        auto record_cmp = [&](const rtw_f16v &Wv, unsigned half16, int blk_) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned long long cm = __ballot(!(Wv[r] < 0.0f));
+                if (cm) {
+                    if (total + 64u > ws.cap) { resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig); total = 0; }
+                    if (!(Wv[r] < 0.0f))
+                        ws.pairs[__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, total))] = lane_const + (unsigned)blk_ * 32u + half16 + (unsigned)r;
+                    total += (unsigned)__popcll(cm);
+                }
+            }
+        };
+#endif
         constexpr unsigned HB = 16u / RTW_SCAN_GROUP;       // mask bits per half block
         {
             rtw_f16v Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[0], zero, 0, 0, 0);
@@ -884,8 +904,12 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
 #ifdef RTW_DUP_EVAL      // time probe: the sign collection twice
             { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
 #endif
+#if RTW_SCAN_CMP
+            if (!(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 0u, blk); }
+#else
             if (RTW_SCAN_SKIP && none(Wv)) mask = (1u << HB) - 1u;          // all negative
             else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }      // (the asm keeps it a real branch: no if-conversion)
+#endif
         }
         {
             // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
@@ -903,9 +927,17 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
 #ifdef RTW_DUP_EVAL
             { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
 #endif
+#if RTW_SCAN_CMP
+            if (!(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 16u, blk); }
+#else
             if (RTW_SCAN_SKIP && none(Wv)) mask = (mask << HB) | ((1u << HB) - 1u);
             else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }
+#endif
         }
+#if RTW_SCAN_CMP
+        clk.lap(2);
+        continue;            // (the candidates of this block are already in the list)
+#endif
         clk.lap(2);
         if (RTW_SCAN_SKIP && !any_cand) {                    // no lane has a candidate in this block: nothing to extract
             if constexpr (!CULLED) { clk.count(7, 1u); clk.count(6, 1u); }

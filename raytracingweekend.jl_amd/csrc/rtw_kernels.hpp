@@ -617,10 +617,18 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             //  loop; 364.0 -> 363.0 ms)
             constexpr bool use_prio = MFMA && sizeof(T) == 4 && RTW_SCAN_PRIO != 0;
             if (use_prio) __builtin_amdgcn_s_setprio(0);
+#ifdef RTW_PROBE_REJ_CAP     // time probe (WRONG image): the loop stops after that many trials -- the upper bound of what parking the stragglers can gain
+            for (int rr = 0; rr < RTW_PROBE_REJ_CAP && pending; ++rr) {
+                len2 = reject_trial<T>(rng, ball, rp);
+                pending = !(len2 <= T(1));
+            }
+            if (pending) len2 = T(1);
+#else
             while (pending) {
                 len2 = reject_trial<T>(rng, ball, rp);
                 pending = !(len2 <= T(1));
             }
+#endif
             if (use_prio) __builtin_amdgcn_s_setprio(1);
         }
         // ---- (F) finish the scatter / the camera ray; ONE normalize for all of them ----
