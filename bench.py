@@ -94,7 +94,7 @@ def parse_args(argv=None):
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the accelerated / scan_valu / end_to_end / depth16 / f64_4k legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the accelerated / scan_valu / ray_pool / end_to_end (value_end_to_end) / depth16 / f64_4k / f64_1080p_d16 legs: ONE kind of launch, for profiling passes")
     ap.add_argument("--group-cull", action="store_true", help="time the opt-in accelerated scan instead of the plain one")
     ap.add_argument("--scan-valu", action="store_true", help="time the all-VALU plain scan (RTW_FLAG_SCAN_VALU) instead of the matrix-pipe filter")
     ap.add_argument("--ray-pool", action="store_true", help="time the opt-in ray-pool kernel (RTW_FLAG_RAY_POOL) instead of the lane-loop kernel")
@@ -447,10 +447,10 @@ def main():
         depth16 = {"value": round(samples_per_step / dt16 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt16 * 1e3, 3),
                    "segments_per_sample": round(st16[0]["segments"] * world / samples_per_step, 4) if world == 1 else None,
                    "note": "same workload at depth 16, the reference's only depth (src/ray_color.jl:14)"}
-    if world == 1 and args.emulate_shard_of <= 1:
+    if extras and world == 1:
         # SURVEY 8(d)'s metric -- the host-buffer entry point (what the Julia ccall binds): render + D2H of the image into the caller's
         # buffer, timed like `value` (the scene upload is cached by the library: the first call, reported separately, pays it)
-        ne = args.steps if extras else 1
+        ne = args.steps
         dte, first_ms, k_ms = wl.timed_host(ne, 1, cull=args.group_cull, depth=depth, valu=args.scan_valu)
         end_to_end = {"value": round(W * H * spp * ne / dte / 1e6, 2), "unit": "Msamples/s", "steps": ne, "ms": round(dte / ne * 1e3, 3),
                       "kernel_ms": round(sum(k_ms) / len(k_ms), 3), "overhead_ms": round(dte / ne * 1e3 - sum(k_ms) / len(k_ms), 3),

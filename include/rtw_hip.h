@@ -111,8 +111,11 @@ typedef struct {
     int32_t n_devices;    /* rtw_render_f32/_f64 only (Julia keyword `devices`): 0 (or 1 with device_ids null) = the one
                              device named by `device`; N >= 1 = the N ordinals in device_ids; -1 = every visible
                              device.  The 8x8 tiles are dealt round-robin to the devices (a stream each); the
-                             shards are gathered in HBM of the first device of the list (peer copies over xGMI)
-                             and the frame is copied to `out` once.  The image is identical for every device list. */
+                             shards are gathered in HBM of the first device of the list -- peer copies with peer
+                             access enabled per device pair (xGMI), a host-staged copy where the platform refuses
+                             it; RTW_FLAG_RCCL_REDUCE: one ncclReduce instead -- and the frame is copied to `out`
+                             once.  The image is identical for every device list; rtw_stats_t.gather_path says
+                             which path ran. */
     int32_t job_pixels;   /* 0 = automatic.  1, 4, 8 or 16: pixels per work-queue job (1x1, 4x1, 8x1, 8x2: rows x columns).
                              Scheduling granularity only -- the image is identical for every value.      */
     const int32_t *device_ids; /* n_devices > 1: HIP ordinals; an ordinal may repeat (its shards then run

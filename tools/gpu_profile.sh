@@ -34,57 +34,7 @@ pmc f32_pool_sqB "$P32 --ray-pool" SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_
 pmc f32_pool_mfma "$P32 --ray-pool" SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 pmc f64_sqA "$B64" GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU
 pmc f64_mfma "$B64" SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16
-python3 - <<PY
-import csv, glob, collections, json, os
-out = {}
-for d in sorted(glob.glob("$O/pmc_*")):
-    if not os.path.isdir(d): continue
-    c = collections.defaultdict(float); dur = []
-    for f in glob.glob(d + "/*counter_collection.csv"):
-        for row in csv.DictReader(open(f)):
-            if "trace_" in row["Kernel_Name"]: c[row["Counter_Name"]] += float(row["Counter_Value"])
-    for f in glob.glob(d + "/*kernel_trace.csv"):
-        for row in csv.DictReader(open(f)):
-            if "trace_" in row["Kernel_Name"]: dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-    out[os.path.basename(d)] = {"counters": dict(c), "launches": len(dur), "kernel_ns": dur}
-# derived figures of the headline kernel: per wave-segment = per 64 ray segments (segments from the bench line of the same workload)
-try:
-    segs = 8177903451.0        # 1920 x 1080 x 1000 spp: the segments the kernel counts (rtw_stats_t.segments; 3.9438 per sample)
-    a, m = out["pmc_f32_sqA"]["counters"], out["pmc_f32_mfma"]["counters"]
-    cyc = a["GRBM_GUI_ACTIVE"] / 8
-    out["derived_f32"] = {"valu_per_wave_segment": a["SQ_INSTS_VALU"] / (segs / 64), "mfma_per_wave_segment": m["SQ_INSTS_MFMA"] / (segs / 64),
-                          "clock_GHz": cyc / out["pmc_f32_sqA"]["kernel_ns"][0], "mfma_busy_frac_of_simd_cycles": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc),
-                          "valu_busy_frac_at_2_cycles": a["SQ_INSTS_VALU"] * 2 / (1024 * cyc), "wait_any_frac_of_wave_cycles": a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"]}
-    wc = a["SQ_WAVE_CYCLES"]
-    out["derived_f32"].update({"wait_inst_any_frac_of_wave_cycles": a["SQ_WAIT_INST_ANY"] / wc, "active_inst_any_frac_of_wave_cycles": a["SQ_ACTIVE_INST_ANY"] / wc,
-                               "issue_busy": (m["SQ_VALU_MFMA_BUSY_CYCLES"] + 2 * a["SQ_INSTS_VALU"]) / (1024 * cyc)})
-    pa, pm_ = out["pmc_f32_pool_sqA"]["counters"], out["pmc_f32_pool_mfma"]["counters"]
-    pb = out["pmc_f32_pool_sqB"]["counters"]
-    pcyc = pa["GRBM_GUI_ACTIVE"] / 8
-    out["derived_f32_pool"] = {"valu_per_wave_segment": pa["SQ_INSTS_VALU"] / (segs / 64), "salu_per_wave_segment": pa["SQ_INSTS_SALU"] / (segs / 64),
-                               "lds_per_wave_segment": pb["SQ_INSTS_LDS"] / (segs / 64), "mfma_per_wave_segment": pm_["SQ_INSTS_MFMA"] / (segs / 64),
-                               "clock_GHz": pcyc / out["pmc_f32_pool_sqA"]["kernel_ns"][0], "mfma_busy_frac_of_simd_cycles": pm_["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * pcyc),
-                               "valu_busy_frac_at_2_cycles": pa["SQ_INSTS_VALU"] * 2 / (1024 * pcyc), "issue_busy": (pm_["SQ_VALU_MFMA_BUSY_CYCLES"] + 2 * pa["SQ_INSTS_VALU"]) / (1024 * pcyc),
-                               "wait_any_frac_of_wave_cycles": pa["SQ_WAIT_ANY"] / pa["SQ_WAVE_CYCLES"], "wait_inst_any_frac_of_wave_cycles": pa["SQ_WAIT_INST_ANY"] / pa["SQ_WAVE_CYCLES"],
-                               "lds_bank_conflict_frac": pm_["SQ_LDS_BANK_CONFLICT"] / max(pm_["SQ_LDS_IDX_ACTIVE"], 1),
-                               "salu_per_wave_segment_lane_loop": a["SQ_INSTS_SALU"] / (segs / 64), "lds_per_wave_segment_lane_loop": out["pmc_f32_sqB"]["counters"]["SQ_INSTS_LDS"] / (segs / 64)}
-except Exception as e:
-    out.setdefault("derived_f32", {})["error"] = str(e)
-json.dump(out, open("$O/pmc_summary.json", "w"), indent=1)
-for k, v in out.items(): print(k, v if k.startswith("derived") else (v["launches"], {a: round(b, 3) for a, b in v["counters"].items()}, [round(x / 1e6, 2) for x in v["kernel_ns"]]))
-# HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: on gfx950 it reports
-# half of the bytes of wide reads); WRITE_SIZE is calibrated on this box (tools/ubench_write_size.hip: 1.00 x for whole-line stores, 32-byte sectors)
-tr = {}
-for key, tag in (("f32_1920x1080_1000spp_d50_plain", "f32"), ("f32_1920x1080_1000spp_d50_cull", "f32_cull"), ("f64_3840x2160_1000spp_d50_plain", "f64")):
-    f, w = out.get("pmc_%s_fetch" % tag), out.get("pmc_%s_write" % tag)
-    if f and w and f["launches"] and w["launches"]:
-        fb = f["counters"].get("FETCH_SIZE", 0) / f["launches"] * 1024
-        wb = w["counters"].get("WRITE_SIZE", 0) / w["launches"] * 1024
-        tr[key] = {"hbm_bytes_per_launch": int(2 * fb + wb), "fetch_size_bytes_raw": int(fb), "write_size_bytes": int(wb),
-                   "source": "rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE / --pmc GRBM_GUI_ACTIVE WRITE_SIZE, one launch each (tools/gpu_profile.sh)"}
-json.dump(tr, open("$O/hbm_traffic.json", "w"), indent=1)
-print(json.dumps(tr, indent=1))
-PY
+python3 $R/tools/pmc_summarise.py $O
 # the bench lines read the HBM traffic of THIS run (box-local copy; the merged gpurun_out/<tag>/hbm_traffic.json is what gets
 # committed as profiles/r04_hbm_traffic.json (likewise r04_pmc_summary.json: `roofline.issue_busy`) -- `traffic_static` in the line says that the figure is not measured by bench.py itself)
 cp $O/hbm_traffic.json $R/profiles/r04_hbm_traffic.json; cp $O/pmc_summary.json $R/profiles/r04_pmc_summary.json
