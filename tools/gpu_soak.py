@@ -87,5 +87,5 @@ if __name__ == "__main__":
     rounds, rays_total, bad_total, seed = scan_rounds(budget * 0.7, seed, say)
     say(f"scan soak: {rounds} rounds, {rays_total} rays, {bad_total} mismatches, {time.time() - t0:.0f} s")
     imgs, bad_imgs, seed = render_rounds(budget - (time.time() - t0), seed, say)
-    say(f"render soak: {imgs} images (4 scan modes), {bad_imgs} mismatches; total {time.time() - t0:.0f} s")
+    say(f"render soak: {imgs} images (all four scan modes + the ray-pool kernel), {bad_imgs} mismatches; total {time.time() - t0:.0f} s")
     sys.exit(1 if (bad_total or bad_imgs) else 0)
