@@ -33,8 +33,18 @@ template <typename T> __device__ __forceinline__ V3<T> vneg(V3<T> a) { return {-
 // StaticArrays dot, length 3: (a1*b1 + a2*b2) + a3*b3
 template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 // StaticArrays normalize(v) = inv(norm(v)) * v
+#ifdef RTW_PROBE_FASTDIV   // time probe (WRONG image): approximate reciprocal square root / reciprocal instead of the IEEE sqrt and divisions
+__device__ __forceinline__ float probe_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double probe_rsq(double x) { return 1.0 / __builtin_sqrt(x); }
+__device__ __forceinline__ float probe_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double probe_rcp(double x) { return 1.0 / x; }
+#endif
 template <typename T> __device__ __forceinline__ V3<T> normalize(V3<T> a) {
+#ifdef RTW_PROBE_FASTDIV
+    T inv = probe_rsq(dot(a, a));
+#else
     T inv = T(1) / t_sqrt(dot(a, a));
+#endif
     return vscale(inv, a);
 }
 // src/vec.jl:19-20: compared against the Float64 literal 1e-5
@@ -118,7 +128,11 @@ template <typename T> __device__ __forceinline__ T reject_trial(Rng &r, bool bal
 }
 // normalize(p) when p.p is already known: StaticArrays' inv(norm(p)) * p with norm = sqrt(p.p)
 template <typename T> __device__ __forceinline__ V3<T> normalize_len2(V3<T> p, T len2) {
+#ifdef RTW_PROBE_FASTDIV
+    return vscale(probe_rsq(len2), p);
+#else
     return vscale(T(1) / t_sqrt(len2), p);
+#endif
 }
 // src/rand.jl:15-22,29: rejection in the unit ball (x,y,z order, boundary inclusive), normalised
 template <typename T> __device__ __forceinline__ V3<T> random_vec3_on_sphere(Rng &r) {
@@ -164,7 +178,12 @@ __device__ __forceinline__ void make_hitrec(V3<T> c, T r, V3<T> o, V3<T> d, T t,
     rec.t = t;
     rec.p = vadd(o, vscale(t, d));
     V3<T> pc = vsub(rec.p, c);
+#ifdef RTW_PROBE_FASTDIV
+    const T ir_ = probe_rcp(r);
+    V3<T> n_out = {pc.x * ir_, pc.y * ir_, pc.z * ir_};
+#else
     V3<T> n_out = {pc.x / r, pc.y / r, pc.z / r};
+#endif
     rec.front = dot(d, n_out) < T(0);
     rec.n = rec.front ? n_out : vneg(n_out);
 }

@@ -587,8 +587,13 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             T du = 0, dv = 0;
             if (jitter) {
                 T r1, r2;
+#ifdef RTW_PROBE_FASTDIV
+                trand(rng, r1); du = r1 * probe_rcp(w_div);
+                trand(rng, r2); dv = r2 * probe_rcp(h_div);
+#else
                 trand(rng, r1); du = r1 / w_div;
                 trand(rng, r2); dv = r2 / h_div;
+#endif
             }
             const JobSlot *S = sh->slot((ref_depth & RTW_REF_MASK) >> 4, P.slot_stride);
             const unsigned px = ref_depth & 15u;
