@@ -1133,6 +1133,8 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
         if (remote) {
             bool direct = false;
             if ((rc = ensure_peer(L[r].ctx, hc->device, root->device, &direct))) break;
+            e = hipSetDevice(hc->device);                 // (ensure_peer switches devices while it enables the access)
+            if (e != hipSuccess) { rc = fail((int)e, "hipSetDevice(%d): %s", hc->device, hipGetErrorString(e)); break; }
             if (direct) {
                 gather_path |= RTW_GATHER_PEER;
                 e = hipSetDevice(hc->device);
