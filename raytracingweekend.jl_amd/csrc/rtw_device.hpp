@@ -394,6 +394,7 @@ template <typename T> struct DevScene {
     float mf_oo_keep;       // 1 - (the ray's share of the relative margin)
     float mf_o1_coef;       // absolute margin per unit of |o|_1
     float mf_o_max;         // rays with a larger |o_k| (or non-unit, non-finite ones) take every sphere as a candidate
+    int n_huge, huge[2];    // spheres tested exactly by every lane instead of through the filter (a ground sphere: candidate of nearly every ray)
 };
 
 // Candidate lists: pass 1 of the scan appends the indices of the spheres whose discriminant is
@@ -812,9 +813,32 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         B1[0] = __builtin_bit_cast(rtw_h8, q10); B1[1] = __builtin_bit_cast(rtw_h8, q11);
         B2[0] = __builtin_bit_cast(rtw_h8, q20); B2[1] = __builtin_bit_cast(rtw_h8, q21);
     }
-    // ---- the result cells ----
-    if constexpr (sizeof(T) == 4) ws.keys[lane] = ~0ull;
-    else { ws.keys[lane] = ~0ull; ws.kidx[lane] = 0u; }
+    // ---- the result cells, initialised with the lane's own exact test of the scene's huge spheres (DevScene::huge; plain scan only):
+    //      the same contract test and the same key / tie rule as pass 2, so the minimum over all candidates is unchanged ----
+    {
+        unsigned long long key0 = ~0ull;
+        [[maybe_unused]] unsigned kidx0 = 0u;
+        if constexpr (!CULLED) {
+            using V4 = typename Vec4<T>::type;
+            for (int hgi = 0; hgi < w.n_huge; ++hgi) {
+                const int si = w.huge[hgi];
+                const V4 sg = src[si];
+                T hb_, disc_, root_ = 0;
+                sphere_disc<T>(sg.x, sg.y, sg.z, sg.w, o, d, hb_, disc_);
+                if (has_ray && sphere_root<T>(hb_, disc_, tmin, (T)__builtin_huge_val(), root_)) {
+                    if constexpr (sizeof(T) == 4) {
+                        const unsigned long long k = ((unsigned long long)__float_as_uint((float)root_) << 32) | (unsigned long long)(0xffffffffu - (unsigned)si);
+                        key0 = k < key0 ? k : key0;
+                    } else {
+                        const unsigned long long tb = (unsigned long long)__double_as_longlong((double)root_);
+                        if (tb < key0 || (tb == key0 && (unsigned)si + 1u > kidx0)) { key0 = tb; kidx0 = (unsigned)si + 1u; }
+                    }
+                }
+            }
+        }
+        if constexpr (sizeof(T) == 4) ws.keys[lane] = key0;
+        else { ws.keys[lane] = key0; ws.kidx[lane] = kidx0; }
+    }
 
     const unsigned lane_const = lane << 16;
     unsigned total = 0;                                   // wave-uniform

@@ -215,6 +215,7 @@ struct rtw_scene_dev {
     void *mf_ops;    // null: the scene's extent is outside what the f16 split covers (the VALU scan is used)
     int mf_blocks;
     float mf_sc, mf_sigma2, mf_oo_keep, mf_o1_coef, mf_o_max;
+    int n_huge, huge[2];   // spheres that pass the filter for nearly every ray (a ground sphere): tested exactly by every lane, their filter rows disabled
     // group-cull mode on the matrix pipe: the same operands in the cluster-major order + one box per block of 32
     void *c_mf_ops, *c_mf_box;
     int c_mf_blocks;
@@ -275,7 +276,7 @@ void material_rows(const SceneT *s, int i, V4 &m0, V4 &m1) {
 
 // cluster-major arrays for the opt-in group-cull scan (rtw_device.hpp, "opt-in accelerated scan")
 template <typename T, typename V4>
-int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, void **ops_out, int *blocks_out);
+int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, void **ops_out, int *blocks_out, int n_skip = 0, const int *skip = nullptr);
 
 template <typename T, typename SceneT>
 int build_cull(const SceneT *s, rtw_scene_dev *h) {
@@ -403,10 +404,13 @@ rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
 // `geom`: n entries; entries with r^2 < -1e29 are padding (never a candidate).  *ops_out / *blocks_out receive the device
 // array; the scale constants in `h` depend on the set of spheres only, so both orders of a scene get the same ones.
 template <typename T, typename V4>
-int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, void **ops_out, int *blocks_out) {
+int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, void **ops_out, int *blocks_out, int n_skip, const int *skip) {
     *ops_out = nullptr; *blocks_out = 0;
     if (n <= 0) return 0;
     auto live = [&](int i) { return i < n && (double)geom[i].w > -1e29; };
+    // `skip`: spheres whose filter ROW is disabled (written like a padding row: never flagged for a ray that uses the filter) because
+    // every lane tests them exactly by itself (DevScene::huge).  They still count for the scales: both orders of a scene share those.
+    auto in_filter = [&](int i) { if (!live(i)) return false; for (int k = 0; k < n_skip; ++k) if (skip[k] == i) return false; return true; };
     double emax = 0;
     for (int i = 0; i < n; ++i) {
         if (!live(i)) continue;
@@ -441,7 +445,7 @@ int build_mfma_operands(const std::vector<V4> &geom, int n, rtw_scene_dev *h, vo
             const int sph = blk * 32 + 16 * ((i >> 2) & 1) + (((i >> 3) << 2) | (i & 3));
             double fq[6] = {0, 0, 0, 0, 0, 0}, fl[3] = {0, 0, 0};
             double kx = -1073741824.0;                                        // padding sphere: k' s^2 = -2^30: W = -2^30 + (q^2 - oo') s^2 < 0
-            if (live(sph)) {
+            if (in_filter(sph)) {
                 const double cx = (double)(float)geom[sph].x, cy = (double)(float)geom[sph].y, cz = (double)(float)geom[sph].z;
                 const double r2 = (double)geom[sph].w, c2 = cx * cx + cy * cy + cz * cz;
                 const double Gs = 1.02 * ((2 * A_S + A_r) * c2 + A_r * r2 + 9 * phi_c * (std::fabs(cx) + std::fabs(cy) + std::fabs(cz)) + 1.5 * phi_k);
@@ -552,7 +556,31 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
         HIP_TRY(hipMalloc(&h->scan, f.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->scan, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (int rc = build_mfma_operands<T>(geom, n, h.get(), &h->mf_ops, &h->mf_blocks)) return rc;
+    // "Huge" spheres: a ground sphere of radius 1000 under spheres of radius 0.2 has a non-negative discriminant for nearly every ray, so
+    // it costs every scan two non-skipped half blocks, an extraction trip and a full 64-entry batch of pass 2.  At most two spheres whose
+    // radius is >= 16 x the median radius are instead tested exactly by every lane for its own ray (hit_world_mfma; same contract test,
+    // same tie rule), and their rows of the filter are disabled.  Scheduling only: the image cannot change.
+    h->n_huge = 0;
+    if (n >= 8) {
+        std::vector<double> ra(n);
+        for (int i = 0; i < n; ++i) ra[i] = std::fabs((double)s->r[i]);
+        std::vector<double> sorted(ra);
+        std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+        const double med = sorted[n / 2];
+        for (int pick = 0; pick < 2; ++pick) {
+            int best = -1;
+            for (int i = 0; i < n; ++i) {
+                if (!(ra[i] >= 16.0 * med) || !std::isfinite(ra[i])) continue;
+                if (h->n_huge > 0 && h->huge[0] == i) continue;
+                if (best < 0 || ra[i] > ra[best]) best = i;
+            }
+            if (best < 0) break;
+            h->huge[h->n_huge++] = best;
+        }
+    }
+    static const bool env_no_huge = getenv("RTW_NO_HUGE") != nullptr && atoi(getenv("RTW_NO_HUGE")) != 0;      // A/B aid
+    if (env_no_huge) h->n_huge = 0;
+    if (int rc = build_mfma_operands<T>(geom, n, h.get(), &h->mf_ops, &h->mf_blocks, h->n_huge, h->huge)) return rc;
     if (int rc = build_cull<T>(s, h.get())) return rc;
     *out = h.release();
     return 0;
@@ -568,6 +596,7 @@ rtw::DevScene<T> dev_scene_of(const rtw_scene_dev *h) {
     S.n = h->n; S.n_pad = h->n_pad;
     S.mf_ops = (const uint4 *)h->mf_ops; S.mf_blocks = h->mf_blocks;
     S.mf_sc = h->mf_sc; S.mf_sigma2 = h->mf_sigma2; S.mf_oo_keep = h->mf_oo_keep; S.mf_o1_coef = h->mf_o1_coef; S.mf_o_max = h->mf_o_max;
+    S.n_huge = h->mf_ops ? h->n_huge : 0; S.huge[0] = h->huge[0]; S.huge[1] = h->huge[1];
     return S;
 }
 

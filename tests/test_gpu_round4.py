@@ -257,3 +257,47 @@ def test_multi_gpu_bench_rccl_matches_one_rank(collective):
     assert two["frame_sha256"] == one["frame_sha256"]
     assert two["collective_ms"] > 0 and two["render_ms_max"] >= two["render_ms_min"] > 0
     assert sorted(r["device"] for r in two["per_rank"]) == [0, 1]
+
+
+# ---- huge spheres tested in-lane (DevScene::huge) -------------------------------------------------------------------------------
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+@pytest.mark.parametrize("layout", ["one", "two_coincident", "two_nested_negative", "three", "first_and_last"])
+def test_huge_spheres_in_lane(oracle, T, layout):
+    """Spheres of radius >= 16 x the median (at most two: a ground sphere) are tested exactly by every lane instead of through the
+    matrix-pipe filter, their filter rows disabled.  The closest hit and the tie rule (the LATER sphere wins an exact tie, src/hit.jl:38-50)
+    must come out as the oracle's: one huge sphere, two coincident ones (every hit is a tie between them), a huge sphere inside a
+    hollow (negative-radius) one, three (the third stays in the filter), huge spheres at both ends of the list."""
+    from test_gpu_round2 import _stress_rays
+    from test_gpu_units import run_unit
+    rng = np.random.default_rng({"one": 1, "two_coincident": 2, "two_nested_negative": 3, "three": 4, "first_and_last": 5}[layout])
+    n = 70
+    cx, cy, cz = [rng.uniform(-8, 8, n) for _ in range(3)]
+    r = rng.uniform(0.1, 0.4, n)
+    big = {"one": [(30, 0, -300.0, 0, 300.0)],
+           "two_coincident": [(10, 0, -300.0, 0, 300.0), (50, 0, -300.0, 0, 300.0)],
+           "two_nested_negative": [(5, 0, 0, 0, 40.0), (6, 0, 0, 0, -60.0)],
+           "three": [(0, 0, -300.0, 0, 300.0), (33, 0, 0, 400.0, 380.0), (69, 100.0, 0, 0, 90.0)],
+           "first_and_last": [(0, 0, -300.0, 0, 300.0), (69, 0, 0, 0, 50.0)]}[layout]
+    for (i, x, y, z, rr) in big:
+        cx[i], cy[i], cz[i], r[i] = x, y, z, rr
+    flat = dict(n=n, cx=cx.astype(T), cy=cy.astype(T), cz=cz.astype(T), r=r.astype(T), kind=np.zeros(n, np.int32),
+                ar=np.ones(n, T), ag=np.ones(n, T), ab=np.ones(n, T), param=np.zeros(n, T))
+    m = 65536
+    rays = _stress_rays(rng, flat, m, T, 8.0)
+    tmin = T(1e-4)
+    ref_idx, ref_t = oracle.hit_world_batch(flat, rays, tmin, np.inf, T)
+    x = np.concatenate([rays.astype(np.float64), np.full((m, 1), float(tmin)), np.full((m, 1), np.inf)], 1)
+    for op in (13, 14):                         # the matrix-pipe scan (huge spheres in-lane) and its culling form (all spheres through the filter)
+        y = run_unit(op, x, 9, T, flat=flat)
+        bad = (y[:, 0].astype(np.int64) != ref_idx) | ((ref_idx >= 0) & (y[:, 1] != ref_t.astype(np.float64)))
+        assert not bad.any(), (op, int(bad.sum()), np.flatnonzero(bad)[:5])
+    if layout == "two_coincident":
+        hits = ref_idx[np.isin(ref_idx, [10, 50])]
+        assert hits.size > 1000 and (hits == 50).all()          # every hit of the pair is an exact tie: the later one
+
+
+def test_huge_sphere_path_off_gives_the_same_frame():
+    """RTW_NO_HUGE=1 (A/B aid, read at scene upload) sends every sphere through the filter again: same frame, same counters"""
+    on = _probe({"x": {}})["x"]
+    off = _probe({"x": {}}, {"RTW_NO_HUGE": "1"})["x"]
+    assert on["sha"] == off["sha"] and on["segments"] == off["segments"]
