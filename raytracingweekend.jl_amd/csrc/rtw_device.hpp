@@ -806,6 +806,35 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         const auto sw = __builtin_amdgcn_permlane32_swap(g0[k], g1[k], false, false);
         h0[k] = sw[0]; h1[k] = sw[1];
     }
+#ifdef RTW_DUP_OPERANDS   // time probe: the ray-operand build (features, f16 splits, word assembly, lane exchange) a second time, same result
+    {
+        float ox2 = ox, oy2 = oy, oz2 = oz, dx2_ = dx, dy2_ = dy, dz2_ = dz;
+        __asm__ volatile("" : "+v"(ox2), "+v"(oy2), "+v"(oz2), "+v"(dx2_), "+v"(dy2_), "+v"(dz2_));
+        const float q_ = __builtin_fmaf(oz2, dz2_, __builtin_fmaf(oy2, dy2_, ox2 * dx2_));
+        const float oo_ = __builtin_fmaf(oz2, oz2, __builtin_fmaf(oy2, oy2, ox2 * ox2));
+        const float o1_ = (__builtin_fabsf(ox2) + __builtin_fabsf(oy2)) + __builtin_fabsf(oz2);
+        const float oop_ = __builtin_fmaf(oo_, w.mf_oo_keep, -(w.mf_o1_coef * o1_));
+        const float tq_ = w.mf_sigma2 * __builtin_fmaf(q_, q_, -oop_);
+        const float fp_[3] = {__builtin_fmaf(-q_, dx2_, ox2) * zs2, __builtin_fmaf(-q_, dy2_, oy2) * zs2, __builtin_fmaf(-q_, dz2_, oz2) * zs2};
+        const float ax = dx2_ * z2, ay = dy2_ * z2, az = dz2_ * z2;
+        const float fq_[6] = {ax * dx2_, ay * dy2_, az * dz2_, (ax + ax) * dy2_, (ax + ax) * dz2_, (ay + ay) * dz2_};
+        unsigned sq_[6], sp_[3];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sq_[k] = split_f16(fq_[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sp_[k] = split_f16(fp_[k]);
+        const float tx_ = ok ? tq_ : tx;
+        const _Float16 t1_ = (_Float16)(tx_ * (1.0f / 32768.0f));
+        const unsigned x23_ = split_f16((tx_ - 32768.0f * (float)t1_) * (1.0f / 16.0f));
+        const unsigned a0[8] = {dup(sq_[0]), cat(sq_[0], sq_[1]), sq_[1], dup(sq_[2]), sq_[5], dup(sp_[0]), cat(sp_[0], sp_[1]), sp_[1]};
+        const unsigned a1[8] = {cat(sq_[2], sq_[3]), sq_[3], dup(sq_[4]), cat(sq_[4], sq_[5]), dup(sp_[2]), cat(sp_[2], sb), ss | ((unsigned)__builtin_bit_cast(unsigned short, t1_) << 16), x23_};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const auto sw2 = __builtin_amdgcn_permlane32_swap(a0[k], a1[k], false, false);
+            __asm__ volatile("" :: "v"(sw2[0]), "v"(sw2[1]));
+        }
+    }
+#endif
     rtw_h8 B1[2], B2[2];
     {
         const uint4 q10 = {h0[0], h0[1], h0[2], h0[3]}, q11 = {h1[0], h1[1], h1[2], h1[3]};

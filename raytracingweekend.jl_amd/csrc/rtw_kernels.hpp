@@ -422,7 +422,11 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             // About a quarter of the lanes end a path per iteration, and each has three channels to convert and add: instead
             // of three rounds at ~25 % lane utilisation the (lane, channel) tasks are dealt to ALL lanes through the wave's
             // candidate list area in LDS (free between two scans): one round for up to 21 paths.
+#ifdef RTW_PROBE_NO_ACCUM   // time probe (WRONG image: black): nothing is added to the pixels -- what the miss path (sky, fixed-point conversion, LDS atomics) costs
+            const bool miss = false;
+#else
             const bool miss = has_ray && idx < 0;
+#endif
             const unsigned long long miss_mask = __ballot(miss);
             if (miss_mask) {
                 unsigned char *scr = reinterpret_cast<unsigned char *>(ws.pairs);

@@ -2,9 +2,10 @@
 # What does each phase of the trace kernel cost?  Library variants that execute ONE phase twice (same results), built on the
 # GPU box; kernel time and VALU instructions per wave-segment of each (1080p, SPP samples).  rejcap2/3: the rejection loop stops after 2 / 3
 # trials (WRONG image: the upper bound of what parking its stragglers could gain); cmp: sign collection by v_cmp -> SGPR masks (same image); fastdiv: approximate reciprocals / reciprocal square roots instead of the
-# IEEE divisions and square roots of the shading (WRONG image: the ceiling of exact-but-cheaper sequences).  usage: tools/gpu_probe_phases.sh [names...]
+# IEEE divisions and square roots of the shading (WRONG image: the ceiling of exact-but-cheaper sequences); operands: the ray-operand build twice;
+# noaccum: nothing is added to the pixels (WRONG image: what the miss path costs).  usage: tools/gpu_probe_phases.sh [names...]
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/probe
-declare -A FL=( [base]="" [mfma]="-DRTW_DUP_MFMA" [eval]="-DRTW_DUP_EVAL" [extract]="-DRTW_DUP_EXTRACT" [resolve]="-DRTW_DUP_RESOLVE_PAIRS" [reject]="-DRTW_DUP_REJECT" [noskip]="-DRTW_SCAN_SKIP=0" [rejcap3]="-DRTW_PROBE_REJ_CAP=3" [rejcap2]="-DRTW_PROBE_REJ_CAP=2" [cmp]="-DRTW_SCAN_CMP=1" [fastdiv]="-DRTW_PROBE_FASTDIV" )
+declare -A FL=( [base]="" [mfma]="-DRTW_DUP_MFMA" [eval]="-DRTW_DUP_EVAL" [extract]="-DRTW_DUP_EXTRACT" [resolve]="-DRTW_DUP_RESOLVE_PAIRS" [reject]="-DRTW_DUP_REJECT" [noskip]="-DRTW_SCAN_SKIP=0" [rejcap3]="-DRTW_PROBE_REJ_CAP=3" [rejcap2]="-DRTW_PROBE_REJ_CAP=2" [cmp]="-DRTW_SCAN_CMP=1" [fastdiv]="-DRTW_PROBE_FASTDIV" [operands]="-DRTW_DUP_OPERANDS" [noaccum]="-DRTW_PROBE_NO_ACCUM" )
 NAMES=${@:-base mfma eval extract resolve reject noskip}
 for n in $NAMES; do make -s -C raytracingweekend.jl_amd/csrc -B OUT=/tmp/librtw_p_$n.so EXTRA="${FL[$n]}" 2>&1 | grep -E "error"; done
 for n in $NAMES; do
