@@ -652,6 +652,7 @@ struct MfmaCull {
     const float *box;
     int blocks;
     float cs[3], rs;      // bounding sphere of the small class (the slab margin grows with the distance to it)
+    int n_huge, huge[2];  // huge spheres (device order), tested in-lane like DevScene::huge
 };
 
 struct WaveScratch {
@@ -842,26 +843,28 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         B1[0] = __builtin_bit_cast(rtw_h8, q10); B1[1] = __builtin_bit_cast(rtw_h8, q11);
         B2[0] = __builtin_bit_cast(rtw_h8, q20); B2[1] = __builtin_bit_cast(rtw_h8, q21);
     }
-    // ---- the result cells, initialised with the lane's own exact test of the scene's huge spheres (DevScene::huge; plain scan only):
+    // ---- the result cells, initialised with the lane's own exact test of the scene's huge spheres (DevScene::huge / MfmaCull::huge):
     //      the same contract test and the same key / tie rule as pass 2, so the minimum over all candidates is unchanged ----
     {
         unsigned long long key0 = ~0ull;
         [[maybe_unused]] unsigned kidx0 = 0u;
-        if constexpr (!CULLED) {
-            using V4 = typename Vec4<T>::type;
-            for (int hgi = 0; hgi < w.n_huge; ++hgi) {
-                const int si = w.huge[hgi];
-                const V4 sg = src[si];
-                T hb_, disc_, root_ = 0;
-                sphere_disc<T>(sg.x, sg.y, sg.z, sg.w, o, d, hb_, disc_);
-                if (has_ray && sphere_root<T>(hb_, disc_, tmin, (T)__builtin_huge_val(), root_)) {
-                    if constexpr (sizeof(T) == 4) {
-                        const unsigned long long k = ((unsigned long long)__float_as_uint((float)root_) << 32) | (unsigned long long)(0xffffffffu - (unsigned)si);
-                        key0 = k < key0 ? k : key0;
-                    } else {
-                        const unsigned long long tb = (unsigned long long)__double_as_longlong((double)root_);
-                        if (tb < key0 || (tb == key0 && (unsigned)si + 1u > kidx0)) { key0 = tb; kidx0 = (unsigned)si + 1u; }
-                    }
+        using V4 = typename Vec4<T>::type;
+        const int n_huge = CULLED ? mc->n_huge : w.n_huge;
+        for (int hgi = 0; hgi < n_huge; ++hgi) {
+            const int si = CULLED ? (hgi == 0 ? mc->huge[0] : mc->huge[1]) : (hgi == 0 ? w.huge[0] : w.huge[1]);      // (no dynamic indexing of a by-value struct: that would live in scratch)
+            const V4 sg = src[si];
+            T hb_, disc_, root_ = 0;
+            sphere_disc<T>(sg.x, sg.y, sg.z, sg.w, o, d, hb_, disc_);
+            if (has_ray && sphere_root<T>(hb_, disc_, tmin, (T)__builtin_huge_val(), root_)) {
+                unsigned tie = (unsigned)si;                       // larger = later in the caller's list (resolve_pairs)
+                if constexpr (CULLED) tie = ((unsigned)orig[si] << 16) | (unsigned)si;
+                if constexpr (sizeof(T) == 4) {
+                    const unsigned low = CULLED ? ((0xffffu - (tie >> 16)) << 16) | (tie & 0xffffu) : 0xffffffffu - tie;
+                    const unsigned long long k = ((unsigned long long)__float_as_uint((float)root_) << 32) | (unsigned long long)low;
+                    key0 = k < key0 ? k : key0;
+                } else {
+                    const unsigned long long tb = (unsigned long long)__double_as_longlong((double)root_);
+                    if (tb < key0 || (tb == key0 && tie + 1u > kidx0)) { key0 = tb; kidx0 = tie + 1u; }
                 }
             }
         }
@@ -1123,9 +1126,10 @@ template <typename T> struct CullScene {
     const uint4 *mf_ops;                   // group cull on the matrix pipe (hit_world_mfma with MfmaCull): operands in this
     const float *mf_box;                   //   device order, one binary32 box per block of 32
     int mf_blocks;
+    int n_huge, huge[2];                   // huge spheres in this order (see DevScene::huge)
 };
 template <typename T> __host__ __device__ inline MfmaCull mfma_cull_of(const CullScene<T> &c) {
-    return MfmaCull{c.mf_ops, c.mf_box, c.mf_blocks, {(float)c.cs[0], (float)c.cs[1], (float)c.cs[2]}, (float)c.rs * 1.000001f + 1e-30f};
+    return MfmaCull{c.mf_ops, c.mf_box, c.mf_blocks, {(float)c.cs[0], (float)c.cs[1], (float)c.cs[2]}, (float)c.rs * 1.000001f + 1e-30f, c.n_huge, {c.huge[0], c.huge[1]}};
 }
 template <typename T> __host__ __device__ inline int cull_exact_count(const CullScene<T> &c) { return c.n_groups_pad * RTW_CULL_GS + ((c.n_big + 31) / 32) * 32; }   // (allocated in whole blocks of 32: dead slots behind the BIG class)
 

@@ -219,6 +219,7 @@ struct rtw_scene_dev {
     // group-cull mode on the matrix pipe: the same operands in the cluster-major order + one box per block of 32
     void *c_mf_ops, *c_mf_box;
     int c_mf_blocks;
+    int c_huge[2];         // the huge spheres' indices in the cluster-major order (n_huge of them)
     // opt-in group-cull mode (RTW_FLAG_GROUP_CULL): cluster-major copies
     void *c_bound, *c_exact, *c_mat0, *c_mat1;
     unsigned short *c_orig;
@@ -353,7 +354,13 @@ int build_cull(const SceneT *s, rtw_scene_dev *h) {
     // box per block of 32 = two clusters (dead clusters left out; the BIG class: everything).  Boxes are binary32,
     // rounded outwards, for both precisions -- the slab test runs in binary32 with the Float32 margin.
     if (h->mf_ops && n_exact > 0) {
-        if (int rc = build_mfma_operands<T>(exact, n_exact, h, &h->c_mf_ops, &h->c_mf_blocks)) return rc;
+        for (int k = 0; k < h->n_huge; ++k) {                     // the huge spheres (tested in-lane) in this order
+            h->c_huge[k] = -1;
+            for (int dI = 0; dI < n_exact; ++dI)
+                if ((double)exact[dI].w > -1e29 && (int)orig[dI] == h->huge[k]) { h->c_huge[k] = dI; break; }
+            if (h->c_huge[k] < 0) return fail(-9, "internal: huge sphere %d not found in the cull layout", h->huge[k]);
+        }
+        if (int rc = build_mfma_operands<T>(exact, n_exact, h, &h->c_mf_ops, &h->c_mf_blocks, h->n_huge, h->c_huge)) return rc;
         const int nb = h->c_mf_blocks;
         std::vector<float> bx((size_t)(nb + 1) * 8, 0.0f);
         for (int b = 0; b <= nb; ++b) {
@@ -393,6 +400,7 @@ rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
     C.cs[0] = (T)h->c_cs[0]; C.cs[1] = (T)h->c_cs[1]; C.cs[2] = (T)h->c_cs[2]; C.rs = (T)h->c_rs;
     C.kappa = sizeof(T) == 4 ? (T)0.00390625 : (T)2.384185791015625e-07;     // 2^-8 / 2^-22
     C.mf_ops = (const uint4 *)h->c_mf_ops; C.mf_box = (const float *)h->c_mf_box; C.mf_blocks = h->c_mf_blocks;
+    C.n_huge = h->c_mf_ops ? h->n_huge : 0; C.huge[0] = h->c_huge[0]; C.huge[1] = h->c_huge[1];
     return C;
 }
 
