@@ -697,6 +697,9 @@ static_assert(RTW_SCAN_GROUP == 1 || RTW_SCAN_GROUP == 2 || RTW_SCAN_GROUP == 4,
                              // if-converted -- both sides executed -- and gains nothing: the sign collection's side is fenced by an asm.)
 #endif
 
+#ifdef RTW_CAND_HIST     // debug build: candidates of the filter per sphere, [2 i] = flagged but contract discriminant < 0, [2 i + 1] = discriminant >= 0
+__device__ unsigned g_cand_hist[8192];
+#endif
 // Walk n entries of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
 struct NoOrig {};
 template <typename T, typename SRC, typename ORIG = NoOrig>
@@ -726,6 +729,9 @@ __device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin,
             const V4 s = sg[m];
             T hb, disc, root = 0;
             sphere_disc<T>(s.x, s.y, s.z, s.w, po, pd, hb, disc);
+#ifdef RTW_CAND_HIST
+            if (valid && sph < 4096u) atomicAdd(&g_cand_hist[2u * sph + (disc < T(0) ? 0u : 1u)], 1u);
+#endif
             if (G > 1 && !__any(valid && !(disc < T(0)))) continue;           // no entry has a candidate at this position
             const bool hit = valid && sphere_root<T>(hb, disc, tmin, (T)__builtin_huge_val(), root);
             unsigned tie = sph;                                  // larger = later in the caller's list

@@ -812,6 +812,21 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
             fprintf(stderr, "[rtw phase profile] matrix-pipe scan: %.1f%% of the (wave, block of 32 spheres) evaluations found no candidate in any lane (%llu of %llu)\n",
                     100.0 * (double)c.phase[6] / (double)c.phase[7], (unsigned long long)c.phase[6], (unsigned long long)c.phase[7]);
     }
+#ifdef RTW_CAND_HIST
+    {
+        static std::vector<unsigned> hh(8192);
+        HIP_TRY(hipMemcpyFromSymbol(hh.data(), HIP_SYMBOL(rtw::g_cand_hist), 8192 * sizeof(unsigned)));
+        unsigned long long fl = 0, tr = 0;
+        for (int i = 0; i < 4096; ++i) { fl += hh[2 * i]; tr += hh[2 * i + 1]; }
+        fprintf(stderr, "[rtw cand hist] cumulative: %llu candidates with discriminant < 0 (filter margin), %llu with discriminant >= 0; per segment %.4f / %.4f\n", fl, tr,
+                (double)fl / (double)std::max<unsigned long long>(1, c.segments), (double)tr / (double)std::max<unsigned long long>(1, c.segments));
+        fprintf(stderr, "[rtw cand hist] first spheres (false, true):");
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %d:(%u,%u)", i, hh[2 * i], hh[2 * i + 1]);
+        fprintf(stderr, " ... last:");
+        for (int i = std::max(0, r->n_spheres - 4); i < r->n_spheres; ++i) fprintf(stderr, " %d:(%u,%u)", i, hh[2 * i], hh[2 * i + 1]);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (c.end_hist[0] == 0xdeadbeefu) {        // (RTW_POOL_WATCHDOG builds: the pool kernel gave up; its state)
         fprintf(stderr, "[rtw pool watchdog]");
         for (int k = 1; k <= 113; ++k) fprintf(stderr, " %u", c.end_hist[k]);
