@@ -32,8 +32,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                     `issue_model` (a MODEL, labelled so): a SIMD issues either a 32-cycle MFMA or a VALU instruction; 4 MFMA + 1
                       v_alignbit_b32 per 64 tests, the alignbit charged 2 cycles (the guide's FMA class) -> 445.6 algorithmic TF, or
                       4.3 cycles (measured slow class, tools/ubench_rates.hip) -> 322.3 TF;
-                    `issue_busy`: (MFMA-busy + 2 x VALU instructions) / SIMD-cycles from the committed PMC pass (static);
-                    `traffic`: HBM bytes per launch from the PMC passes kept in profiles/ (static), plus the algorithmic HBM figure.
+                    `issue_busy`: (MFMA-busy + 2 x VALU instructions) / SIMD-cycles, and `traffic`: HBM bytes per launch (FETCH_SIZE x 2 +
+                      WRITE_SIZE) -- MEASURED IN THIS RUN by three `rocprofv3 --pmc` passes of this script that the default run spawns (one
+                      launch each, ~12 s each; `traffic_static` false); when rocprofv3 is missing or a pass fails, the committed figures of
+                      profiles/ (`traffic_static` true).  Plus the algorithmic HBM figure.
   value        -- device-resident rate (scene in HBM, image left in HBM), as the task's bench contract prescribes;
                   `value_end_to_end` is SURVEY 8(d)'s metric: the host-buffer entry point rtw_render_* timed the same way (barrier +
                   synchronize around K calls; render + D2H of the image into the caller's buffer; scene upload cached by the library).
@@ -98,6 +100,7 @@ def parse_args(argv=None):
     ap.add_argument("--group-cull", action="store_true", help="time the opt-in accelerated scan instead of the plain one")
     ap.add_argument("--scan-valu", action="store_true", help="time the all-VALU plain scan (RTW_FLAG_SCAN_VALU) instead of the matrix-pipe filter")
     ap.add_argument("--ray-pool", action="store_true", help="time the opt-in ray-pool kernel (RTW_FLAG_RAY_POOL) instead of the lane-loop kernel")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes that measure roofline.traffic / issue_busy in this run")
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per pixel (0 = library default rule)")
     ap.add_argument("--emulate-shard-of", type=int, default=0,
                     help="analysis only: on ONE GPU render shard 0 of N (what each rank of an N-GPU run does)")
@@ -355,6 +358,54 @@ def roofline_of(wl, k_s, tests_per_launch, seg_per_sample, *, cull, valu, world,
     }
 
 
+def live_pmc(dtype, width, spp, depth, timeout_s=90):
+    """HBM traffic and issue-busy of ONE launch of this workload, measured in this run: three `rocprofv3 --pmc` passes of this script
+    itself (`--steps 1 --warmup 0 --no-extras`: exactly one trace-kernel launch each; FETCH_SIZE and WRITE_SIZE in separate passes, as
+    MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled: its gfx950 correction; KiB units).  Returns None when rocprofv3 is not there, a
+    pass fails or times out -- the line then carries the committed figures of profiles/ (marked static)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    base = tempfile.mkdtemp(prefix="rtw_pmc_", dir="/tmp")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--dtype", dtype,
+           "--width", str(width), "--spp", str(spp), "--depth", str(depth)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = {}
+    try:
+        for tag, counters in (("fetch", ["GRBM_GUI_ACTIVE", "FETCH_SIZE"]), ("write", ["GRBM_GUI_ACTIVE", "WRITE_SIZE"]),
+                              ("issue", ["GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA"])):
+            d = os.path.join(base, tag)
+            r = subprocess.run([exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + cmd,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            rows = [row for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True) for row in csv.DictReader(open(f))
+                    if "trace_" in row["Kernel_Name"]]
+            if not rows:
+                return None
+            first = min(int(row["Dispatch_Id"]) for row in rows)
+            if len(set(row["Dispatch_Id"] for row in rows)) != 1:
+                return None                                     # (must be ONE launch: per-launch figures)
+            for row in rows:
+                if int(row["Dispatch_Id"]) == first:
+                    out[(tag, row["Counter_Name"])] = out.get((tag, row["Counter_Name"]), 0.0) + float(row["Counter_Value"])
+        fetch, write = out[("fetch", "FETCH_SIZE")] * 1024, out[("write", "WRITE_SIZE")] * 1024
+        simd = N_SIMD * out[("issue", "GRBM_GUI_ACTIVE")] / 8
+        return {"traffic": int(2 * fetch + write), "fetch_size_bytes_raw": int(fetch), "write_size_bytes": int(write),
+                "issue_busy": {"mfma_busy": round(out[("issue", "SQ_VALU_MFMA_BUSY_CYCLES")] / simd, 4),
+                               "valu_x2": round(2 * out[("issue", "SQ_INSTS_VALU")] / simd, 4),
+                               "sum": round((out[("issue", "SQ_VALU_MFMA_BUSY_CYCLES")] + 2 * out[("issue", "SQ_INSTS_VALU")]) / simd, 4),
+                               "valu_instructions": int(out[("issue", "SQ_INSTS_VALU")]), "mfma_instructions": int(out[("issue", "SQ_INSTS_MFMA")]),
+                               "source": "rocprofv3 --pmc pass of this command spawned by this run (one launch)"}}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 def cpu_legs(wl, seconds):
     """The CPU oracle on this box's host cores, bounded sample: [16-thread leg (if the box has 16), all-threads leg]."""
     import rtw_oracle as O
@@ -465,6 +516,13 @@ def main():
         k_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
         roofline = roofline_of(wl, k_s, sum(tests) / len(tests), all_segments / (samples_per_step * args.steps),
                                cull=args.group_cull, valu=args.scan_valu, world=world, shard_div=shard_div)
+        if extras and world == 1 and not (args.group_cull or args.scan_valu or args.ray_pool) and not args.no_live_pmc:
+            pm = live_pmc(args.dtype, W, spp, depth)            # ~3 x 12 s; None on any failure (the static figures stay)
+            if pm:
+                roofline["traffic"], roofline["traffic_static"] = pm["traffic"], False
+                roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by THIS run (one launch each; FETCH_SIZE x 2 + WRITE_SIZE)"
+                roofline["traffic_detail"] = {"fetch_size_bytes_raw": pm["fetch_size_bytes_raw"], "write_size_bytes": pm["write_size_bytes"]}
+                roofline["issue_busy"] = pm["issue_busy"]
         cpu = cpu16 = None
         legs = []
         if world == 1 and not args.no_cpu_baseline:
