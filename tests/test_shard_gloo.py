@@ -36,7 +36,15 @@ def _worker(rank, world, port, q):
             mask = R.owned_pixel_mask(g["width"], idx, cnt)
             return torch.from_numpy(np.where(mask[..., None], img, np.float32(0)).astype(np.float32))
 
-        fb = R.render_sharded(render_shard, g["width"])
+        order = []
+
+        def render_shard_logged(idx, cnt):
+            order.append("render")
+            return render_shard(idx, cnt)
+
+        # after_render: bench.py records a HIP event there to time the render and the collective separately (collective_ms)
+        fb = R.render_sharded(render_shard_logged, g["width"], after_render=lambda: order.append("hook"))
+        assert order == ["render", "hook"], order
 
         def render_compact(idx, cnt):
             # stand-in for render_into(..., compact=True): this shard's tiles only, tile-major
@@ -76,6 +84,9 @@ def test_render_sharded_single_process(rtw):
     import torch
     fb = rtw.render_sharded(lambda i, n: torch.full((2, 2), float(n)), 96)
     assert fb.tolist() == [[1.0, 1.0], [1.0, 1.0]]
+    calls = []
+    rtw.render_sharded(lambda i, n: torch.zeros(4), 96, after_render=lambda: calls.append(1))
+    assert calls == [1]
     with pytest.raises(ValueError):
         rtw.render_sharded(lambda i, n: torch.zeros(1), 96, mode="scatter")
 
