@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define RTW_ABI_VERSION 2
+#define RTW_ABI_VERSION 2   /* unchanged in round 4: the new rtw_params.flags bits (RTW_FLAG_RAY_POOL, RTW_FLAG_RCCL_REDUCE) and the use of
+                               rtw_stats_t's former `reserved` word as `gather_path` do not move any field; a list of ONE device is accepted */
 
 /* Material kinds: Lambertian / Metal / Dielectric (src/material.jl:3-5, 25-29, 37-39). */
 enum { RTW_LAMBERTIAN = 0, RTW_METAL = 1, RTW_DIELECTRIC = 2 };
