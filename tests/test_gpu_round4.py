@@ -301,3 +301,33 @@ def test_huge_sphere_path_off_gives_the_same_frame():
     on = _probe({"x": {}})["x"]
     off = _probe({"x": {}}, {"RTW_NO_HUGE": "1"})["x"]
     assert on["sha"] == off["sha"] and on["segments"] == off["segments"]
+
+
+# ---- the bench line -----------------------------------------------------------------------------------------------------------
+def test_bench_line_contract_and_live_counters():
+    """`python bench.py` (small spp): every key of the bench contract, the roofline object in the fixed yard-sticks, HBM traffic and issue-busy
+    MEASURED by the run itself (rocprofv3 --pmc passes it spawns; `traffic_static` false), the ray-pool leg with the same frame hash, the
+    end-to-end value next to the device-resident one, and the reference's published configuration as its own leg."""
+    from test_gpu_round3 import _bench
+    p, d = _bench(["--steps", "1", "--warmup", "1", "--spp", "16", "--cpu-seconds", "0.5"], timeout=900)
+    assert p.returncode == 0 and d is not None, p.stderr[-3000:]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"] and d["higher_is_better"] is True
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / 2500.0) < 1e-3
+    assert r["algorithmic"]["fp32_vector_peak"] == 157.3 and r["issue_model"]["model"] is True
+    assert r["traffic_static"] is False and r["traffic"] > 0 and r["traffic_detail"]["write_size_bytes"] >= 1920 * 1080 * 3 * 4 * 0.9
+    assert 0.0 < r["issue_busy"]["sum"] < 1.2 and r["issue_busy"]["mfma_instructions"] > 0
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port"
+    assert d["value_end_to_end"] and d["end_to_end"]["value"] == d["value_end_to_end"] and d["kernel_only"] >= d["value"] * 0.9
+    assert d["ray_pool"]["frame_sha256_equal"] is True and d["ray_pool"]["block_threads"] == 1024
+    assert d["accelerated"]["frame_sha256_equal"] is True and d["scan_valu"]["frame_sha256_equal"] is True
+    assert d["collective_ms"] == 0.0 and d["render_ms_max"] == d["render_ms_min"] > 0
+    # (the f64 legs belong to the headline workload only: --spp 16 is not it)
+    assert d["f64_4k"] is None and d["f64_1080p_d16"] is None
