@@ -24,8 +24,9 @@
 extern "C" {
 #endif
 
-#define RTW_ABI_VERSION 2   /* unchanged in round 4: the new rtw_params.flags bits (RTW_FLAG_RAY_POOL, RTW_FLAG_RCCL_REDUCE) and the use of
-                               rtw_stats_t's former `reserved` word as `gather_path` do not move any field; a list of ONE device is accepted */
+#define RTW_ABI_VERSION 3   /* round 5: no field moved, but the DEFAULT image changed -- the deciding arithmetic of hit(::Sphere) is now the
+                               reference's own un-fused order (RTW_FLAG_NUMERICS_* below; version 2's image = RTW_FLAG_NUMERICS_CONTRACT) --
+                               and the measurement switches read from the environment are honoured only under RTW_ENABLE_TEST_AIDS=1 */
 
 /* Material kinds: Lambertian / Metal / Dielectric (src/material.jl:3-5, 25-29, 37-39). */
 enum { RTW_LAMBERTIAN = 0, RTW_METAL = 1, RTW_DIELECTRIC = 2 };
@@ -88,6 +89,21 @@ typedef struct {
  * the path), one communicator per device list is kept until rtw_shutdown().  The devices of the list must be distinct.  Default (0):
  * compact shards gathered with peer copies (1/N of a frame per device instead of a whole one). */
 #define RTW_FLAG_RCCL_REDUCE 16
+/* The deciding arithmetic of the ray-sphere test, src/hit.jl:16-18.  In Float32 the choice is visible: on
+ * scene_random_spheres the contract form traces 4 % fewer ray segments per sample than the reference's own order and its image is
+ * brighter by 0.003 in the mean (fewer tmin re-hits of the r = 1000 ground sphere); Float64 images agree to the last few ulps.
+ *   default (neither bit)            `oc . r.dir` and `oc . oc` as StaticArrays' dot evaluates them -- (x1 y1 + x2 y2) + x3 y3, no FMA:
+ *                                    a callee, which @fastmath does not rewrite --, c = oc.oc - r^2, disc = half_b^2 - c, one rounding each
+ *   RTW_FLAG_NUMERICS_REFERENCE_FMA  the same with the last step contracted, disc = fma(half_b, half_b, -c): what an FMA target gives if
+ *                                    the square carries LLVM's `contract` flag
+ *   RTW_FLAG_NUMERICS_CONTRACT       ABI 2's arithmetic: half_b, r^2 - |oc|^2 and disc as three FMA chains
+ * The two bits exclude each other.  tools/julia_kat.jl + tools/check_julia_kat.py decide between them on a Julia box. */
+#define RTW_FLAG_NUMERICS_CONTRACT 32
+#define RTW_FLAG_NUMERICS_REFERENCE_FMA 64
+/* Measurement / test switches of the ENVIRONMENT (RTW_SCAN, RTW_POOL, RTW_JOB_PIXELS, RTW_ROWS_SHIFT, RTW_NO_HUGE,
+ * RTW_DEBUG_REMOTE_SHARDS, RTW_DEBUG_NO_PEER, RTW_PHASE_PROFILE, RTW_DRAIN_PROFILE, RTW_DEBUG) are honoured only when the master switch
+ * RTW_ENABLE_TEST_AIDS=1 is set too (read once per process).  Without it a stray variable changes nothing: a render's kernel choice, launch
+ * geometry and gather path depend on rtw_params alone. */
 /* rtw_stats_t.gather_path (bits): how the shards of the last multi-device render reached the first device */
 #define RTW_GATHER_PEER 1         /* hipMemcpyPeerAsync with peer access enabled in both directions (xGMI)      */
 #define RTW_GATHER_HOST_STAGED 2  /* no peer access on this platform: D2H into pinned memory, H2D on the root   */
@@ -181,7 +197,8 @@ int rtw_stats(rtw_stats_t *out);
  *       12 exact 64.64 fixed-point accumulation of 8 doubles
  *       13 hit_world_mfma (pass 1 on the matrix pipe: the trace kernel's plain scan), scene staged in LDS;
  *          tmin of ray 0 serves the whole launch, tmax is +inf
- *       14 the same with block culling (RTW_FLAG_GROUP_CULL on the matrix pipe), cull layout staged in LDS  */
+ *       14 the same with block culling (RTW_FLAG_GROUP_CULL on the matrix pipe), cull layout staged in LDS
+ *   bits 8-9 of `op`: the numerics mode of the ray-sphere test for ops 0, 8 - 11, 13, 14 (0 reference, 1 contract, 2 reference_fma)  */
 int rtw_unit_f32(int op, int count, const void *in, void *out, const rtw_scene_f32 *scene,
                  const rtw_camera_f32 *cam);
 int rtw_unit_f64(int op, int count, const void *in, void *out, const rtw_scene_f64 *scene,

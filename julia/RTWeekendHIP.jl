@@ -47,7 +47,7 @@ end
 
 function __init__()
     v = ccall((:rtw_abi_version, LIB), Cint, ())
-    v == 2 || error("librtw_hip.so has ABI version $v; this shim binds version 2 (include/rtw_hip.h)")
+    v == 3 || error("librtw_hip.so has ABI version $v; this shim binds version 3 (include/rtw_hip.h)")
 end
 
 matkind(::Lambertian) = Int32(0)
@@ -64,18 +64,23 @@ matparam(m::Dielectric{T}) where T = m.ir
 last_error() = unsafe_string(ccall((:rtw_last_error, LIB), Cstring, ()))
 
 """
-    render(scene, cam, image_width=400, n_samples=1; depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, group_cull=false, scan_valu=false, ray_pool=false, rccl_reduce=false)
+    render(scene, cam, image_width=400, n_samples=1; depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, numerics=:reference, group_cull=false, scan_valu=false, ray_pool=false, rccl_reduce=false)
 
 Drop-in for `RayTracingWeekend.render` (src/render.jl:8-44) on MI355X.  Keyword extras only.
 `depth=16` is the reference's hard-wired `ray_color` default (src/ray_color.jl:14).
 `devices=:all` uses every visible GPU, `devices=[0, 1, 2]` the listed ones (the 8x8 tiles are dealt
 round-robin to the devices inside the library; the image is identical for any device list).
+`numerics` selects the deciding arithmetic of `hit(::Sphere)` (src/hit.jl:16-18): `:reference` (default) = the reference's own order -- StaticArrays' un-fused
+`dot`, one rounding per written operation --, `:reference_fma` = the same with `disc = fma(half_b, half_b, -c)`, `:contract` = three FMA chains
+(RTW_FLAG_NUMERICS_*; in Float32 the choice moves the image mean by 0.003 and the work by 4 %: `tools/julia_kat.jl` tells which one this Julia build emits).
 `group_cull=true` selects the opt-in culling scan (RTW_FLAG_GROUP_CULL), `scan_valu=true` the all-VALU form of either
 scan (RTW_FLAG_SCAN_VALU, for A/B measurements), `ray_pool=true` the ray-pool kernel (RTW_FLAG_RAY_POOL): same image bit for bit in every mode.
 `rccl_reduce=true` (with `devices`): the shards are put together by one ncclReduce inside the library (RTW_FLAG_RCCL_REDUCE) instead of peer copies.
 """
 function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=1;
-                depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, group_cull=false, scan_valu=false, ray_pool=false, rccl_reduce=false) where T <: Union{Float32,Float64}
+                depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, numerics=:reference, group_cull=false, scan_valu=false, ray_pool=false, rccl_reduce=false) where T <: Union{Float32,Float64}
+    numerics in (:reference, :contract, :reference_fma) || throw(ArgumentError("numerics must be :reference, :contract or :reference_fma"))
+    nflags = numerics === :contract ? 32 : numerics === :reference_fma ? 64 : 0         # RTW_FLAG_NUMERICS_CONTRACT / _REFERENCE_FMA
     image_height = image_width ÷ (16//9)                       # src/render.jl:11-12
     n = length(scene)
     cx = Vector{T}(undef, n); cy = similar(cx); cz = similar(cx); r = similar(cx)
@@ -95,7 +100,7 @@ function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=
     n_devices = devices === :all ? -1 : (length(ids) > 1 ? length(ids) : 0)
     length(ids) == 1 && (device = ids[1])
     rc = GC.@preserve cx cy cz r kind ar ag ab param img ids begin
-        params = Ref(CParams(image_width, image_height, n_samples, depth, seed, n_chunks, 0, 1, device, 1, (group_cull ? 1 : 0) | (scan_valu ? 4 : 0) | (ray_pool ? 8 : 0) | (rccl_reduce ? 16 : 0),
+        params = Ref(CParams(image_width, image_height, n_samples, depth, seed, n_chunks, 0, 1, device, 1, (group_cull ? 1 : 0) | (scan_valu ? 4 : 0) | (ray_pool ? 8 : 0) | (rccl_reduce ? 16 : 0) | nflags,
                              n_devices, 0, length(ids) > 1 ? pointer(ids) : Ptr{Int32}(C_NULL)))
         cscene = Ref(CScene{T}(n, pointer(cx), pointer(cy), pointer(cz), pointer(r), pointer(kind),
                                pointer(ar), pointer(ag), pointer(ab), pointer(param)))

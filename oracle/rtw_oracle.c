@@ -21,9 +21,16 @@
  * src/rand.jl:7,12 (rand(rng), rand(rng, T)).
  * ------------------------------------------------------------------------------------------ */
 typedef struct { uint64_t x, y; } orng;
-typedef struct { orng rng; uint64_t draws, segments; } octx;
+typedef struct { orng rng; uint64_t draws, segments; int numerics; } octx;
 typedef struct { double r, g, b; } c3;
 static _Thread_local uint64_t g_cand_disc = 0, g_cand_fwd = 0;   /* workload statistics */
+static int g_unit_numerics = RTW_NUMERICS_REFERENCE;             /* what the unit-level exports use (rtwo_set_numerics) */
+int rtwo_set_numerics(int mode) {
+    if (mode < 0 || mode > RTW_NUMERICS_REFERENCE_FMA2) return -2;
+    g_unit_numerics = mode;
+    return 0;
+}
+int rtwo_get_numerics(void) { return g_unit_numerics; }
 
 static inline uint64_t rotl64(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
 

@@ -21,15 +21,21 @@
  *              restated from memory; the reference holds no test or golden vector for them.
  *              tools/julia_kat.jl dumps the vectors that would pin them on a Julia box.
  *
- * NUMERICS CONTRACT (shared with the HIP kernels)
+ * NUMERICS (shared with the HIP kernels)
  *   - IEEE-754 binary32/binary64, round-to-nearest-even, correctly rounded + - * / sqrt,
  *     subnormals kept.  Compiled with -ffp-contract=off: NO implicit FMA anywhere.
- *   - Explicit FMA in exactly one place, the ray-sphere discriminant (hit_sphere):
- *        half_b = fma(oc.z,d.z, fma(oc.y,d.y, oc.x*d.x))
- *        nc     = fma(-oc.z,oc.z, fma(-oc.y,oc.y, fma(-oc.x,oc.x, r*r)))      (= r^2 - |oc|^2)
- *        disc   = fma(half_b,half_b, nc)
- *     (a legal @fastmath contraction of src/hit.jl:16-18).
- *   - everything else: one rounding per written operation, left to right as in the reference.
+ *   - One rounding per written operation, left to right as the reference writes it -- INCLUDING, since round 5, the
+ *     ray-sphere discriminant of src/hit.jl:16-18 (RTW_NUMERICS_REFERENCE, the default):
+ *        half_b = (oc.x*d.x + oc.y*d.y) + oc.z*d.z          StaticArrays' dot: a callee, @fastmath does not reach it
+ *        c      = ((oc.x^2 + oc.y^2) + oc.z^2) - r*r
+ *        disc   = half_b*half_b - c
+ *   - NUMERICS MODES (rtwo_params.numerics; rtwo_set_numerics for the unit-level exports): the other evaluations an
+ *     LLVM build of that function could produce, kept selectable so that one Julia run decides (tools/julia_kat.jl):
+ *        RTW_NUMERICS_CONTRACT        rounds 1-4: half_b, r^2 - |oc|^2 and disc as three FMA chains
+ *        RTW_NUMERICS_REFERENCE_FMA   un-fused dots, disc = fma(half_b, half_b, -c)
+ *        RTW_NUMERICS_REFERENCE_FMA2  ... and c = fma(-r, r, oc.oc) too          (oracle only)
+ *     In Float32 the choice is NOT noise: the contract form traces 4 % fewer segments per sample on
+ *     scene_random_spheres and shifts the image mean by +0.003 (fewer tmin re-hits of the r = 1000 ground sphere).
  *   - Float32 mode is the reference's *mixed* precision: geometry, RNG floats and
  *     scatter in binary32; sky colour, attenuation product and pixel accumulation in binary64.
  */
@@ -74,6 +80,8 @@ typedef struct {
 
 enum { RTW_RNG_PIXEL_STREAM = 0, RTW_RNG_REF_SERIAL = 1 };
 enum { RTW_PRODUCT_REFERENCE = 0, RTW_PRODUCT_FORWARD = 1 };
+/* the deciding arithmetic of hit(::Sphere) (src/hit.jl:16-18): see "NUMERICS MODES" above and sphere_test_ */
+enum { RTW_NUMERICS_REFERENCE = 0, RTW_NUMERICS_CONTRACT = 1, RTW_NUMERICS_REFERENCE_FMA = 2, RTW_NUMERICS_REFERENCE_FMA2 = 3 };
 
 typedef struct {
     int32_t width, height;   /* height = width div 16//9 (src/render.jl:11-12); both passed    */
@@ -90,6 +98,7 @@ typedef struct {
                                 ((att1*att2)*...)*sky, what the iterative GPU loop computes   */
     int32_t omp_threads;     /* worker threads for the timing leg (<=0: all)                   */
     int32_t gamma;           /* 1: sqrt per channel (rgb_gamma2, src/vec.jl:22); 0: linear mean */
+    int32_t numerics;        /* RTW_NUMERICS_*: the deciding arithmetic of hit(::Sphere)               */
 } rtwo_params;
 
 typedef struct {
@@ -176,6 +185,9 @@ int rtwo_scene_random_spheres_f64(uint64_t seed, double *cx, double *cy, double 
                                   int32_t *kind, double *ar, double *ag, double *ab, double *param);
 
 int rtwo_max_threads(void);
+/* the numerics mode of the unit-level exports above (hit_sphere, hit_world, hit_world_batch, ray_color); process-wide */
+int rtwo_set_numerics(int mode);
+int rtwo_get_numerics(void);
 /* exact fixed-point sum of binary64 values, rounded once (the PIXEL_STREAM pixel accumulation) */
 double rtwo_fx_sum(const double *x, int n, int *poisoned);
 

@@ -14,6 +14,47 @@ LIB_PATH = os.path.join(_HERE, "librtw_oracle.so")
 
 PIXEL_STREAM, REF_SERIAL = 0, 1
 PRODUCT_REFERENCE, PRODUCT_FORWARD = 0, 1
+# the deciding arithmetic of hit(::Sphere), src/hit.jl:16-18 (rtw_oracle.h "NUMERICS MODES")
+NUMERICS_REFERENCE, NUMERICS_CONTRACT, NUMERICS_REFERENCE_FMA, NUMERICS_REFERENCE_FMA2 = 0, 1, 2, 3
+NUMERICS = {"reference": 0, "contract": 1, "reference_fma": 2, "reference_fma2": 3}
+_default_numerics = NUMERICS_REFERENCE
+
+
+def numerics_code(n):
+    """'reference' / 'contract' / 'reference_fma' / 'reference_fma2', a code 0..3, or None (= the current default)"""
+    if n is None:
+        return _default_numerics
+    if isinstance(n, str):
+        return NUMERICS[n]
+    n = int(n)
+    if n not in NUMERICS.values():
+        raise ValueError(f"unknown numerics mode {n}")
+    return n
+
+
+def set_numerics(n):
+    """Default numerics mode of render() / pixel_samples() AND the mode of the unit-level helpers (hit_sphere, hit_world,
+    hit_world_batch, ray_color), which have no parameter for it.  Returns the previous mode."""
+    global _default_numerics
+    prev = _default_numerics
+    _default_numerics = numerics_code(n)
+    if lib().rtwo_set_numerics(_default_numerics) != 0:
+        raise ValueError(f"unknown numerics mode {n}")
+    return prev
+
+
+class numerics:
+    """with O.numerics('contract'): ..."""
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.prev = set_numerics(self.n)
+        return self
+
+    def __exit__(self, *a):
+        set_numerics(self.prev)
+        return False
 
 
 def build(force=False):
@@ -48,7 +89,7 @@ class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("seed", C.c_uint64), ("rng_mode", C.c_int32), ("ref_threads", C.c_int32),
                 ("n_chunks", C.c_int32), ("product_order", C.c_int32), ("omp_threads", C.c_int32),
-                ("gamma", C.c_int32)]
+                ("gamma", C.c_int32), ("numerics", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -126,7 +167,7 @@ def camera_to_dict(Cm, T):
 
 
 def render(flat_scene, cam, width, height, spp, *, T=np.float32, max_depth=16, seed=1, rng_mode=PIXEL_STREAM,
-           ref_threads=1, n_chunks=None, product_order=PRODUCT_FORWARD, omp_threads=0, gamma=True):
+           ref_threads=1, n_chunks=None, product_order=PRODUCT_FORWARD, omp_threads=0, gamma=True, numerics=None):
     """Oracle render.  Returns (img[i, j, c] of dtype T, stats dict)."""
     L = lib()
     S, keep = make_scene(flat_scene, T)
@@ -134,7 +175,7 @@ def render(flat_scene, cam, width, height, spp, *, T=np.float32, max_depth=16, s
     if n_chunks is None or n_chunks <= 0:
         n_chunks = default_n_chunks(spp)
     P = Params(int(width), int(height), int(spp), int(max_depth), int(seed), int(rng_mode), int(ref_threads),
-               int(n_chunks), int(product_order), int(omp_threads), 1 if gamma else 0)
+               int(n_chunks), int(product_order), int(omp_threads), 1 if gamma else 0, numerics_code(numerics))
     out = np.empty(int(width) * int(height) * 3, dtype=T)
     st = Stats()
     fn = L.rtwo_render_f64 if _is64(T) else L.rtwo_render_f32
@@ -147,14 +188,14 @@ def render(flat_scene, cam, width, height, spp, *, T=np.float32, max_depth=16, s
 
 
 def pixel_samples(flat_scene, cam, width, height, spp, i, j, *, T=np.float32, max_depth=16, seed=1, n_chunks=None,
-                  product_order=PRODUCT_FORWARD):
+                  product_order=PRODUCT_FORWARD, numerics=None):
     """Radiance of every sample of pixel (i, j) (1-based) in PIXEL_STREAM mode, in sample order -> float64 [spp, 3]."""
     if n_chunks is None:
         n_chunks = default_n_chunks(spp)
     S, keep = make_scene(flat_scene, T)
     Cm = make_camera(cam, T)
     P = Params(int(width), int(height), int(spp), int(max_depth), int(seed), PIXEL_STREAM, 1,
-               int(n_chunks), int(product_order), 1, 0)
+               int(n_chunks), int(product_order), 1, 0, numerics_code(numerics))
     out = np.zeros((int(spp), 3), np.float64)
     fn = getattr(lib(), "rtwo_pixel_samples_f64" if _is64(T) else "rtwo_pixel_samples_f32")
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]

@@ -67,13 +67,30 @@ static inline void FN(random_vec2_in_disk_)(octx *c, T *px, T *py) {
 typedef struct { T t; V3 p, n; int front; } FN(hitrec_);
 #define HREC FN(hitrec_)
 
-/* src/hit.jl:12-29: the quadratic and the root selection.  Discriminant in the contracted
- * form of the numerics contract (rtw_oracle.h). */
-static inline int FN(sphere_test_)(V3 c, T r, V3 o, V3 d, T tmin, T tmax, T *t_out) {
+/* src/hit.jl:12-29: the quadratic and the root selection.  The deciding arithmetic is selectable (rtw_oracle.h,
+ * "NUMERICS MODES"):
+ *   RTW_NUMERICS_REFERENCE      what src/hit.jl:16-18 evaluates as written: `oc . r.dir` and `oc . oc` are calls of
+ *                               StaticArrays' dot -- a callee, which @fastmath does not rewrite -- i.e. the un-fused
+ *                               (x1 y1 + x2 y2) + x3 y3; `- s.radius^2` and `half_b^2 - a*c` are one rounding each
+ *                               (x^2 = llvm.powi(x, 2) = x * x WITHOUT fast-math flags: no contraction with the fsub)
+ *   RTW_NUMERICS_REFERENCE_FMA  the same, but the last step contracted: disc = fma(half_b, half_b, -c) -- what LLVM emits
+ *                               on an FMA target if the square does carry the `contract` flag
+ *   RTW_NUMERICS_REFERENCE_FMA2 ... and c = fma(-r, r, oc.oc) as well (both fsub-of-a-square sites contracted)
+ *   RTW_NUMERICS_CONTRACT       rounds 1-4: three FMA chains (a legal @fastmath contraction only if @fastmath reached into dot) */
+static inline __attribute__((always_inline)) int FN(sphere_test_)(int numerics, V3 c, T r, V3 o, V3 d, T tmin, T tmax, T *t_out) {
     V3 oc = FN(vsub_)(o, c);                                            /* :13 */
-    T half_b = FMA_T(oc.z, d.z, FMA_T(oc.y, d.y, oc.x * d.x));          /* :16 */
-    T nc = FMA_T(-oc.z, oc.z, FMA_T(-oc.y, oc.y, FMA_T(-oc.x, oc.x, r * r))); /* -(:17) */
-    T disc = FMA_T(half_b, half_b, nc);                                 /* :18 (a == 1) */
+    T half_b, disc, nc;
+    if (numerics == RTW_NUMERICS_CONTRACT) {
+        half_b = FMA_T(oc.z, d.z, FMA_T(oc.y, d.y, oc.x * d.x));        /* :16 */
+        nc = FMA_T(-oc.z, oc.z, FMA_T(-oc.y, oc.y, FMA_T(-oc.x, oc.x, r * r))); /* -(:17) */
+        disc = FMA_T(half_b, half_b, nc);                               /* :18 (a == 1) */
+    } else {
+        half_b = FN(dot_)(oc, d);                                       /* :16  StaticArrays dot, no FMA */
+        T ococ = FN(dot_)(oc, oc);
+        T cc = numerics == RTW_NUMERICS_REFERENCE_FMA2 ? FMA_T(-r, r, ococ) : ococ - r * r;   /* :17 */
+        disc = numerics == RTW_NUMERICS_REFERENCE ? half_b * half_b - cc : FMA_T(half_b, half_b, -cc);   /* :18 (a == 1: a*c == c) */
+        nc = -cc;
+    }
     if (disc < (T)0) return 0;                                          /* :19 */
     g_cand_disc++;                       /* workload statistics only */
     if (half_b < (T)0 || nc > (T)0) g_cand_fwd++;
@@ -95,9 +112,9 @@ static inline void FN(make_rec_)(V3 c, T r, V3 o, V3 d, T t, HREC *rec) {
     rec->front = FN(dot_)(d, n_out) < (T)0;                             /* :7 */
     rec->n = rec->front ? n_out : FN(vneg_)(n_out);                     /* :8 */
 }
-static inline int FN(hit_sphere_)(V3 c, T r, V3 o, V3 d, T tmin, T tmax, HREC *rec) {
+static inline int FN(hit_sphere_)(int numerics, V3 c, T r, V3 o, V3 d, T tmin, T tmax, HREC *rec) {
     T t;
-    if (!FN(sphere_test_)(c, r, o, d, tmin, tmax, &t)) return 0;
+    if (!FN(sphere_test_)(numerics, c, r, o, d, tmin, tmax, &t)) return 0;
     FN(make_rec_)(c, r, o, d, t, rec);
     return 1;
 }
@@ -105,19 +122,28 @@ static inline int FN(hit_sphere_)(V3 c, T r, V3 o, V3 d, T tmin, T tmax, HREC *r
 /* src/hit.jl:38-50: closest hit, linear scan, `closest` shrinks, later sphere wins exact ties.
  * The reference materialises a HitRecord per accepted candidate; only the last one survives,
  * so it is built once for the winner (same values). */
-static inline int FN(hit_world_)(const SCENE_T *w, V3 o, V3 d, T tmin, T tmax, HREC *best) {
+static inline __attribute__((always_inline)) int FN(hit_world_n_)(const int numerics, const SCENE_T *w, V3 o, V3 d, T tmin, T tmax, HREC *best) {
     T closest = tmax;
     int idx = -1;
     for (int i = 0; i < w->n; ++i) {
         V3 c = {w->cx[i], w->cy[i], w->cz[i]};
         T t;
-        if (FN(sphere_test_)(c, w->r[i], o, d, tmin, closest, &t)) { closest = t; idx = i; }
+        if (FN(sphere_test_)(numerics, c, w->r[i], o, d, tmin, closest, &t)) { closest = t; idx = i; }
     }
     if (idx >= 0) {
         V3 c = {w->cx[idx], w->cy[idx], w->cz[idx]};
         FN(make_rec_)(c, w->r[idx], o, d, closest, best);
     }
     return idx;
+}
+/* (the mode is decided once per scan, outside the loop over the spheres: each call below inlines the loop with a CONSTANT mode) */
+static inline int FN(hit_world_)(int numerics, const SCENE_T *w, V3 o, V3 d, T tmin, T tmax, HREC *best) {
+    switch (numerics) {
+        case RTW_NUMERICS_CONTRACT: return FN(hit_world_n_)(RTW_NUMERICS_CONTRACT, w, o, d, tmin, tmax, best);
+        case RTW_NUMERICS_REFERENCE_FMA: return FN(hit_world_n_)(RTW_NUMERICS_REFERENCE_FMA, w, o, d, tmin, tmax, best);
+        case RTW_NUMERICS_REFERENCE_FMA2: return FN(hit_world_n_)(RTW_NUMERICS_REFERENCE_FMA2, w, o, d, tmin, tmax, best);
+        default: return FN(hit_world_n_)(RTW_NUMERICS_REFERENCE, w, o, d, tmin, tmax, best);
+    }
 }
 
 /* ---- light transport (src/light.jl) ------------------------------------------------------ */
@@ -202,7 +228,7 @@ static c3 FN(ray_color_rec_)(octx *c, const SCENE_T *w, V3 o, V3 d, int depth) {
     if (depth <= 0) return zero;                                        /* :15-17 */
     HREC rec;
     c->segments++;
-    int idx = FN(hit_world_)(w, o, d, (T)1e-4, T_INF, &rec);            /* :19 */
+    int idx = FN(hit_world_)(c->numerics, w, o, d, (T)1e-4, T_INF, &rec); /* :19 */
     if (idx < 0) return FN(skycolor_)(d);                               /* :36 */
     V3 albedo; T param;
     FN(mat_of_)(w, idx, &albedo, &param);
@@ -220,7 +246,7 @@ static c3 FN(ray_color_fwd_)(octx *c, const SCENE_T *w, V3 o, V3 d, int depth) {
         if (depth <= 0) return zero;
         HREC rec;
         c->segments++;
-        int idx = FN(hit_world_)(w, o, d, (T)1e-4, T_INF, &rec);
+        int idx = FN(hit_world_)(c->numerics, w, o, d, (T)1e-4, T_INF, &rec);
         if (idx < 0) {
             c3 sky = FN(skycolor_)(d);
             c3 out = {thr.r * sky.r, thr.g * sky.g, thr.b * sky.b};
@@ -301,7 +327,7 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
             if (rem > 0) {
                 if (k <= rem) { f += k - 1; l += k; } else { f += rem; l += rem; }
             }
-            octx c; c.draws = 0; c.segments = 0;
+            octx c; c.draws = 0; c.segments = 0; c.numerics = P->numerics;
             g_cand_disc = 0; g_cand_fwd = 0;
             rng_seed_int((uint64_t)k, &c.rng);
             for (int i = f; i <= l; ++i)
@@ -331,7 +357,7 @@ int FN(rtwo_render_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_params *P
             T u = (T)((double)j / (double)W);
             T v = (T)((double)(H - i) / (double)H);
             fxacc fx; memset(&fx, 0, sizeof fx);
-            octx c; c.draws = 0; c.segments = 0;
+            octx c; c.draws = 0; c.segments = 0; c.numerics = P->numerics;
             g_cand_disc = 0; g_cand_fwd = 0;
             for (int ch = 0; ch < nch_eff; ++ch) {
                 rng_stream(P->seed, (uint64_t)pix, (uint64_t)ch, &c.rng);
@@ -371,7 +397,7 @@ int FN(rtwo_pixel_samples_)(const SCENE_T *w, const CAMERA_T *cam, const rtwo_pa
     long pix = (long)(j - 1) * H + (i - 1);
     T u = (T)((double)j / (double)W);
     T v = (T)((double)(H - i) / (double)H);
-    octx c; c.draws = 0; c.segments = 0;
+    octx c; c.draws = 0; c.segments = 0; c.numerics = P->numerics;
     for (int ch = 0; ch < nch_eff; ++ch) {
         rng_stream(P->seed, (uint64_t)pix, (uint64_t)ch, &c.rng);
         int s1 = (ch + 1) * cs < P->spp ? (ch + 1) * cs : P->spp;
@@ -411,7 +437,7 @@ void FN(rtwo_default_camera_)(const T lookfrom[3], const T lookat[3], const T vu
 /* src/scenes.jl:49-84, drawn from Xoroshiro128Plus(seed) (== reseed!() then build on thread 1) */
 int FN(rtwo_scene_random_spheres_)(uint64_t seed, T *cx, T *cy, T *cz, T *r, int32_t *kind,
                                    T *ar, T *ag, T *ab, T *param) {
-    octx c; c.draws = 0; c.segments = 0;
+    octx c; c.draws = 0; c.segments = 0; c.numerics = 0;
     rng_seed_int(seed, &c.rng);
     int n = 0;
 #define PUSH(X, Y, Z, R, K, A0, A1, A2, P)                                                   \
@@ -468,13 +494,13 @@ static inline void FN(rec_out_)(const HREC *h, T rec[8]) {
 }
 int FN(rtwo_hit_sphere_)(const T c[3], T r, const T o[3], const T d[3], T tmin, T tmax, T rec[8]) {
     HREC h;
-    if (!FN(hit_sphere_)(FN(ld3_)(c), r, FN(ld3_)(o), FN(ld3_)(d), tmin, tmax, &h)) return 0;
+    if (!FN(hit_sphere_)(g_unit_numerics, FN(ld3_)(c), r, FN(ld3_)(o), FN(ld3_)(d), tmin, tmax, &h)) return 0;
     FN(rec_out_)(&h, rec);
     return 1;
 }
 int FN(rtwo_hit_world_)(const SCENE_T *w, const T o[3], const T d[3], T tmin, T tmax, T rec[8]) {
     HREC h;
-    int idx = FN(hit_world_)(w, FN(ld3_)(o), FN(ld3_)(d), tmin, tmax, &h);
+    int idx = FN(hit_world_)(g_unit_numerics, w, FN(ld3_)(o), FN(ld3_)(d), tmin, tmax, &h);
     if (idx >= 0) FN(rec_out_)(&h, rec);
     return idx;
 }
@@ -484,13 +510,13 @@ void FN(rtwo_hit_world_batch_)(const SCENE_T *w, const T *rays, long n, T tmin, 
     for (long i = 0; i < n; ++i) {
         HREC h;
         h.t = (T)0;
-        idx[i] = FN(hit_world_)(w, FN(ld3_)(rays + 6 * i), FN(ld3_)(rays + 6 * i + 3), tmin, tmax, &h);
+        idx[i] = FN(hit_world_)(g_unit_numerics, w, FN(ld3_)(rays + 6 * i), FN(ld3_)(rays + 6 * i + 3), tmin, tmax, &h);
         t[i] = idx[i] >= 0 ? h.t : (T)0;
     }
 }
 int FN(rtwo_scatter_)(int kind, const T albedo[3], T param, const T d[3], const T rec[8],
                       uint64_t state[2], T out[9]) {
-    octx c; c.draws = 0; c.segments = 0; c.rng.x = state[0]; c.rng.y = state[1];
+    octx c; c.draws = 0; c.segments = 0; c.numerics = g_unit_numerics; c.rng.x = state[0]; c.rng.y = state[1];
     HREC h; h.t = rec[0]; h.p = FN(ld3_)(rec + 1); h.n = FN(ld3_)(rec + 4); h.front = rec[7] != (T)0;
     SCAT s = FN(scatter_)(&c, kind, FN(ld3_)(albedo), param, FN(ld3_)(d), &h);
     FN(st3_)(out, s.o); FN(st3_)(out + 3, s.d); FN(st3_)(out + 6, s.att);
@@ -498,7 +524,7 @@ int FN(rtwo_scatter_)(int kind, const T albedo[3], T param, const T d[3], const 
     return 1;
 }
 void FN(rtwo_get_ray_)(const CAMERA_T *cam, T s, T t, uint64_t state[2], T out[6]) {
-    octx c; c.draws = 0; c.segments = 0; c.rng.x = state[0]; c.rng.y = state[1];
+    octx c; c.draws = 0; c.segments = 0; c.numerics = g_unit_numerics; c.rng.x = state[0]; c.rng.y = state[1];
     V3 o, d;
     FN(get_ray_)(&c, cam, s, t, &o, &d);
     FN(st3_)(out, o); FN(st3_)(out + 3, d);
@@ -506,7 +532,7 @@ void FN(rtwo_get_ray_)(const CAMERA_T *cam, T s, T t, uint64_t state[2], T out[6
 }
 void FN(rtwo_ray_color_)(const SCENE_T *w, const T o[3], const T d[3], int depth, int product_order,
                          uint64_t state[2], double out[3]) {
-    octx c; c.draws = 0; c.segments = 0; c.rng.x = state[0]; c.rng.y = state[1];
+    octx c; c.draws = 0; c.segments = 0; c.numerics = g_unit_numerics; c.rng.x = state[0]; c.rng.y = state[1];
     c3 col = product_order == RTW_PRODUCT_FORWARD
                  ? FN(ray_color_fwd_)(&c, w, FN(ld3_)(o), FN(ld3_)(d), depth)
                  : FN(ray_color_rec_)(&c, w, FN(ld3_)(o), FN(ld3_)(d), depth);

@@ -122,16 +122,53 @@ FLAG_COMPACT_TILES = 2   # include/rtw_hip.h RTW_FLAG_COMPACT_TILES
 FLAG_SCAN_VALU = 4       # include/rtw_hip.h RTW_FLAG_SCAN_VALU
 FLAG_RAY_POOL = 8        # include/rtw_hip.h RTW_FLAG_RAY_POOL
 FLAG_RCCL_REDUCE = 16    # include/rtw_hip.h RTW_FLAG_RCCL_REDUCE
+FLAG_NUMERICS_CONTRACT = 32        # include/rtw_hip.h RTW_FLAG_NUMERICS_CONTRACT
+FLAG_NUMERICS_REFERENCE_FMA = 64   # include/rtw_hip.h RTW_FLAG_NUMERICS_REFERENCE_FMA
 GATHER_PEER, GATHER_HOST_STAGED, GATHER_RCCL, GATHER_SAME_DEVICE = 1, 2, 4, 8    # rtw_stats_t.gather_path bits
-ABI_VERSION = 2
+ABI_VERSION = 3
+
+# The deciding arithmetic of the ray-sphere test (src/hit.jl:16-18; include/rtw_hip.h RTW_FLAG_NUMERICS_*).
+# name -> (rtw_params.flags bits, the mode code in bits 8-9 of a unit op)
+NUMERICS = {"reference": (0, 0), "contract": (FLAG_NUMERICS_CONTRACT, 1), "reference_fma": (FLAG_NUMERICS_REFERENCE_FMA, 2)}
+_default_numerics = "reference"
+
+
+def set_default_numerics(name):
+    """The mode ``render`` / ``DeviceRenderer`` / ``make_params`` use when none is named.  Returns the previous default."""
+    global _default_numerics
+    if name not in NUMERICS:
+        raise ValueError(f"numerics must be one of {sorted(NUMERICS)}")
+    prev, _default_numerics = _default_numerics, name
+    return prev
+
+
+def numerics_name(numerics=None):
+    name = _default_numerics if numerics is None else numerics
+    if name not in NUMERICS:
+        raise ValueError(f"numerics must be one of {sorted(NUMERICS)}")
+    return name
+
+
+def numerics_flags(numerics=None):
+    return NUMERICS[numerics_name(numerics)][0]
+
+
+def numerics_unit_bits(numerics=None):
+    """what to OR into the ``op`` of rtw_unit_f32/_f64"""
+    return NUMERICS[numerics_name(numerics)][1] << 8
 
 
 def make_params(width, height, spp, max_depth=16, seed=1, n_chunks=0, shard_index=0, shard_count=1,
-                device=-1, gamma=1, flags=0, devices=None, job_pixels=0):
-    """``devices``: None / int ordinal -> one device; "all" -> every visible device (n_devices = -1);
+                device=-1, gamma=1, flags=0, devices=None, job_pixels=0, numerics=None):
+    """``numerics``: "reference" (default) / "contract" / "reference_fma", or None = the module default
+    (``set_default_numerics``); ignored when ``flags`` already names a mode.
+    ``devices``: None / int ordinal -> one device; "all" -> every visible device (n_devices = -1);
     a sequence of ordinals -> that device list (host-buffer entry points only)."""
+    flags = int(flags)
+    if not flags & (FLAG_NUMERICS_CONTRACT | FLAG_NUMERICS_REFERENCE_FMA):
+        flags |= numerics_flags(numerics)
     P = Params(int(width), int(height), int(spp), int(max_depth), int(seed), int(n_chunks),
-               int(shard_index), int(shard_count), int(device), int(gamma), int(flags), 0, int(job_pixels), None)
+               int(shard_index), int(shard_count), int(device), int(gamma), flags, 0, int(job_pixels), None)
     if devices is None:
         return P
     if isinstance(devices, str):

@@ -148,14 +148,36 @@ template <typename T> __device__ __forceinline__ void random_vec2_in_disk(Rng &r
 }
 
 // ---- intersection (src/hit.jl) ---------------------------------------------------------------
-// The per-sphere test of src/hit.jl:13-18 in the contracted form of the numerics contract.
-// r2 = r*r is precomputed at upload (same bits as computing it here).
+// The per-sphere test of src/hit.jl:13-18.  r2 = r*r is precomputed at upload (same bits as computing it here).
+// The deciding arithmetic is selectable (include/rtw_hip.h, RTW_FLAG_NUMERICS_*):
+//   NUM_REFERENCE (default)  as the reference evaluates it: `oc . r.dir` and `oc . oc` are StaticArrays' dot -- a callee that
+//                            @fastmath does not rewrite: (x1 y1 + x2 y2) + x3 y3, no FMA --, then  c = oc.oc - r^2  and
+//                            disc = half_b^2 - c  with one rounding each
+//   NUM_REFERENCE_FMA        the same with the last step contracted: disc = fma(half_b, half_b, -c)
+//   NUM_CONTRACT             rounds 1 - 4: half_b, r^2 - |oc|^2 and disc as three FMA chains
+// (this file is compiled with -ffp-contract=off: the un-fused forms stay un-fused).
+enum { NUM_REFERENCE = 0, NUM_CONTRACT = 1, NUM_REFERENCE_FMA = 2 };
+template <int N> struct NumTag { static constexpr int value = N; };
+template <typename T, int NUM>
+__device__ __forceinline__ void sphere_disc_n(T cx, T cy, T cz, T r2, V3<T> o, V3<T> d, T &half_b, T &disc) {
+    const T ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
+    if constexpr (NUM == NUM_CONTRACT) {
+        half_b = t_fma(ocz, d.z, t_fma(ocy, d.y, ocx * d.x));
+        const T nc = t_fma(-ocz, ocz, t_fma(-ocy, ocy, t_fma(-ocx, ocx, r2)));
+        disc = t_fma(half_b, half_b, nc);
+    } else {
+        half_b = (ocx * d.x + ocy * d.y) + ocz * d.z;                       // src/hit.jl:16
+        const T c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;             // :17
+        if constexpr (NUM == NUM_REFERENCE) disc = half_b * half_b - c;     // :18 (a == 1)
+        else disc = t_fma(half_b, half_b, -c);
+    }
+}
+// `num` is wave-uniform (a kernel argument): real scalar branches
 template <typename T>
-__device__ __forceinline__ void sphere_disc(T cx, T cy, T cz, T r2, V3<T> o, V3<T> d, T &half_b, T &disc) {
-    T ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
-    half_b = t_fma(ocz, d.z, t_fma(ocy, d.y, ocx * d.x));
-    T nc = t_fma(-ocz, ocz, t_fma(-ocy, ocy, t_fma(-ocx, ocx, r2)));
-    disc = t_fma(half_b, half_b, nc);
+__device__ __forceinline__ void sphere_disc(int num, T cx, T cy, T cz, T r2, V3<T> o, V3<T> d, T &half_b, T &disc) {
+    if (num == NUM_REFERENCE) sphere_disc_n<T, NUM_REFERENCE>(cx, cy, cz, r2, o, d, half_b, disc);
+    else if (num == NUM_CONTRACT) sphere_disc_n<T, NUM_CONTRACT>(cx, cy, cz, r2, o, d, half_b, disc);
+    else sphere_disc_n<T, NUM_REFERENCE_FMA>(cx, cy, cz, r2, o, d, half_b, disc);
 }
 // src/hit.jl:19-29: root selection against [tmin, closest]; returns true and the root on a hit
 template <typename T>
@@ -395,6 +417,7 @@ template <typename T> struct DevScene {
     float mf_o1_coef;       // absolute margin per unit of |o|_1
     float mf_o_max;         // rays with a larger |o_k| (or non-unit, non-finite ones) take every sphere as a candidate
     int n_huge, huge[2];    // spheres tested exactly by every lane instead of through the filter (a ground sphere: candidate of nearly every ray)
+    int numerics;           // NUM_*: the deciding arithmetic of sphere_disc for this render (set per launch, not per upload)
 };
 
 // Candidate lists: pass 1 of the scan appends the indices of the spheres whose discriminant is
@@ -434,14 +457,14 @@ struct NoClock { __device__ __forceinline__ void lap(int) {} __device__ __forcei
 //           ties resolve exactly as in the reference.  `src` is the scene copy in LDS (or the
 //           global array for scenes too large for LDS); the loop is software-pipelined: entry
 //           c+1's index and sphere are fetched while entry c is tested.
-template <typename T, int STRIDE, typename SRC>
-__device__ __forceinline__ void resolve_candidates(SRC src, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
-                                                   const unsigned short *list, int cnt) {
+template <typename T, int STRIDE, int NUM, typename SRC>
+__device__ __forceinline__ void resolve_candidates_n(SRC src, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
+                                                     const unsigned short *list, int cnt) {
     using V4 = typename Vec4<T>::type;
     auto test = [&](int c, int i, const V4 &s) {
         if (c < cnt) {
             T hb, disc, root;
-            sphere_disc<T>(s.x, s.y, s.z, s.w, o, d, hb, disc);
+            sphere_disc_n<T, NUM>(s.x, s.y, s.z, s.w, o, d, hb, disc);
             if (sphere_root<T>(hb, disc, tmin, closest, root)) { closest = root; idx = i; }
         }
     };
@@ -456,6 +479,14 @@ __device__ __forceinline__ void resolve_candidates(SRC src, V3<T> o, V3<T> d, T 
         sa = src[ia];
         if (__any(c + 1 < cnt)) test(c + 1, ib, sb);
     }
+}
+// (the numerics mode is wave-uniform: one scalar branch per call, not per candidate)
+template <typename T, int STRIDE, typename SRC>
+__device__ __forceinline__ void resolve_candidates(int num, SRC src, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
+                                                   const unsigned short *list, int cnt) {
+    if (num == NUM_REFERENCE) resolve_candidates_n<T, STRIDE, NUM_REFERENCE>(src, o, d, tmin, closest, idx, list, cnt);
+    else if (num == NUM_CONTRACT) resolve_candidates_n<T, STRIDE, NUM_CONTRACT>(src, o, d, tmin, closest, idx, list, cnt);
+    else resolve_candidates_n<T, STRIDE, NUM_REFERENCE_FMA>(src, o, d, tmin, closest, idx, list, cnt);
 }
 
 template <typename T, int STRIDE, typename SRC, typename CLK = NoClock>
@@ -480,7 +511,8 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
     for (int k = 0; k < G; ++k) A[k] = ldg(k);
     // Pass 1 only has to produce a SUPERSET of {spheres whose contract discriminant is >= 0}: pass 2 applies the
     // exact test to every candidate.
-    //   Float32: the contract discriminant itself (10 VALU + 1 v_alignbit per sphere).
+    //   Float32: the discriminant itself, in the render's numerics mode (contract form: 10 VALU + 1 v_alignbit per sphere; the
+    //   reference's un-fused form: 16 + 1).
     //   Float64: a conservative binary32 FILTER (12 VALU + 1 v_alignbit; an FP64 instruction costs two issue slots,
     //   the exact form would be 10 x 2 + 1).  With o, c, d, r^2 rounded to binary32 (u = 2^-24) and the same
     //   operation order, the computed  W = fma(hb, hb, fma(nc, 1 - 2^-18, G))  satisfies
@@ -500,7 +532,7 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
         of = {(float)o.x, (float)o.y, (float)o.z};
         df = {(float)d.x, (float)d.y, (float)d.z};
     }
-    auto test1 = [&](const Unit &sp, uint32_t &mask) {
+    auto test1 = [&](auto tag, const Unit &sp, uint32_t &mask) {
         if constexpr (F64) {
             const float ocx = of.x - sp.v[0], ocy = of.y - sp.v[1], ocz = of.z - sp.v[2];
             const float hb = __builtin_fmaf(ocz, df.z, __builtin_fmaf(ocy, df.y, ocx * df.x));
@@ -510,10 +542,12 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
             mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(W), 31);
         } else {
             T hb, disc;
-            sphere_disc<T>(sp.v[0], sp.v[1], sp.v[2], sp.v[3], o, d, hb, disc);
+            sphere_disc_n<T, decltype(tag)::value>(sp.v[0], sp.v[1], sp.v[2], sp.v[3], o, d, hb, disc);
             mask = __builtin_amdgcn_alignbit(mask, sign_word(disc), 31);
         }
     };
+    // (the whole scan loop once per numerics mode: the mode is decided outside the loop, not per sphere)
+    auto scan = [&](auto tag) {
     for (int base = 0; base < w.n_pad; base += RTW_SPHERE_WORD) {
         uint32_t mask = 0;
         // the last word may be partial: n_pad is a multiple of one group (G), not of 32
@@ -525,26 +559,26 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
             // Scalar loads return out of order, so every wait is lgkmcnt(0).  To keep a group's
             // loads in flight for a whole group of VALU work, the next group's loads are issued
             // right AFTER the wait that the current group's first use forces, never before it.
-            test1(A[0], mask);
+            test1(tag, A[0], mask);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < G; ++k) B[k] = ldg(off + G + k);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 1; k < G; ++k) test1(A[k], mask);
+            for (int k = 1; k < G; ++k) test1(tag, A[k], mask);
             __builtin_amdgcn_sched_barrier(0);
-            test1(B[0], mask);
+            test1(tag, B[0], mask);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < G; ++k) A[k] = ldg(off + 2 * G + k);      // next group (tail-padded)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 1; k < G; ++k) test1(B[k], mask);
+            for (int k = 1; k < G; ++k) test1(tag, B[k], mask);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (ngroups & 1) {                        // odd group count: the scene's last group, already in A
 #pragma unroll
-            for (int k = 0; k < G; ++k) test1(A[k], mask);
+            for (int k = 0; k < G; ++k) test1(tag, A[k], mask);
         }
         clk.lap(2);
         uint32_t m = ~mask;                       // bit 31 = sphere `base`, bit 0 = sphere base+31
@@ -564,7 +598,7 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
             while (__any(m != 0u)) {
                 if (__any(cnt >= RTW_LIST_CAP)) {     // some lane's list is full: resolve all lists now
                     clk.lap(4);
-                    resolve_candidates<T, STRIDE>(src, o, d, tmin, closest, idx, list, cnt);
+                    resolve_candidates<T, STRIDE>(w.numerics, src, o, d, tmin, closest, idx, list, cnt);
                     cnt = 0;
                     clk.lap(5);
                 }
@@ -573,10 +607,15 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
         }
         clk.lap(4);
     }
-    resolve_candidates<T, STRIDE>(src, o, d, tmin, closest, idx, list, cnt);
+    };
+    if constexpr (F64) scan(NumTag<NUM_REFERENCE>{});        // (the binary32 filter does not depend on the mode)
+    else if (w.numerics == NUM_REFERENCE) scan(NumTag<NUM_REFERENCE>{});
+    else if (w.numerics == NUM_CONTRACT) scan(NumTag<NUM_CONTRACT>{});
+    else scan(NumTag<NUM_REFERENCE_FMA>{});
+    resolve_candidates<T, STRIDE>(w.numerics, src, o, d, tmin, closest, idx, list, cnt);
 #ifdef RTW_DUP_RESOLVE   // instruction-count probe: the final resolve twice (idempotent: same winner)
     { T c2 = tmax; int i2 = -1; __asm__ volatile("" : "+v"(c2), "+v"(i2));
-      resolve_candidates<T, STRIDE>(src, o, d, tmin, c2, i2, list, cnt);
+      resolve_candidates<T, STRIDE>(w.numerics, src, o, d, tmin, c2, i2, list, cnt);
       __asm__ volatile("" :: "v"(c2), "v"(i2)); }
 #endif
     clk.lap(5);
@@ -703,7 +742,7 @@ __device__ unsigned g_cand_hist[8192];
 // Walk n entries of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
 struct NoOrig {};
 template <typename T, typename SRC, typename ORIG = NoOrig>
-__device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
+__device__ __forceinline__ void resolve_pairs(int num, SRC src, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
     constexpr bool CULLED = !__is_same(ORIG, NoOrig);      // device order != the caller's order: ties go by orig[], the key carries both
     constexpr unsigned G = RTW_SCAN_GROUP;
     using V4 = typename Vec4<T>::type;
@@ -728,7 +767,7 @@ __device__ __forceinline__ void resolve_pairs(SRC src, V3<T> o, V3<T> d, T tmin,
             const unsigned sph = sph0 + m;
             const V4 s = sg[m];
             T hb, disc, root = 0;
-            sphere_disc<T>(s.x, s.y, s.z, s.w, po, pd, hb, disc);
+            sphere_disc<T>(num, s.x, s.y, s.z, s.w, po, pd, hb, disc);
 #ifdef RTW_CAND_HIST
             if (valid && sph < 4096u) atomicAdd(&g_cand_hist[2u * sph + (disc < T(0) ? 0u : 1u)], 1u);
 #endif
@@ -860,7 +899,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             const int si = CULLED ? (hgi == 0 ? mc->huge[0] : mc->huge[1]) : (hgi == 0 ? w.huge[0] : w.huge[1]);      // (no dynamic indexing of a by-value struct: that would live in scratch)
             const V4 sg = src[si];
             T hb_, disc_, root_ = 0;
-            sphere_disc<T>(sg.x, sg.y, sg.z, sg.w, o, d, hb_, disc_);
+            sphere_disc<T>(w.numerics, sg.x, sg.y, sg.z, sg.w, o, d, hb_, disc_);
             if (has_ray && sphere_root<T>(hb_, disc_, tmin, (T)__builtin_huge_val(), root_)) {
                 unsigned tie = (unsigned)si;                       // larger = later in the caller's list (resolve_pairs)
                 if constexpr (CULLED) tie = ((unsigned)orig[si] << 16) | (unsigned)si;
@@ -965,7 +1004,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             for (int r = 0; r < 16; ++r) {
                 const unsigned long long cm = __ballot(!(Wv[r] < 0.0f));
                 if (cm) {
-                    if (total + 64u > ws.cap) { resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig); total = 0; }
+                    if (total + 64u > ws.cap) { resolve_pairs<T>(w.numerics, src, o, d, tmin, ws, total, lane, orig); total = 0; }
                     if (!(Wv[r] < 0.0f))
                         ws.pairs[__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, total))] = lane_const + (unsigned)blk_ * 32u + half16 + (unsigned)r;
                     total += (unsigned)__popcll(cm);
@@ -973,15 +1012,34 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             }
         };
 #endif
+        // the filter values of one half block (32 spheres x 32 rays): two chained MFMAs.  Time probes (tools/gpu_probe_phases.sh):
+        // -DRTW_DUP_MFMA=k executes the pair k more times (same result); -DRTW_PROBE_NO_MFMA replaces it by a constant "no candidate"
+        // (WRONG image: only the in-lane huge spheres are ever hit -- what the kernel costs per wave-segment WITHOUT the matrix pipe).
+        auto filter_pair = [&](const uint4 &a1, const uint4 &a2, const rtw_h8 &b1, const rtw_h8 &b2) -> rtw_f16v {
+#ifdef RTW_PROBE_NO_MFMA
+            rtw_f16v Wn = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+            const uint4 u1 = __builtin_bit_cast(uint4, b1), u2 = __builtin_bit_cast(uint4, b2);
+            __asm__ volatile("" :: "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w), "v"(a2.x), "v"(a2.y), "v"(a2.z), "v"(a2.w));   // (the operands stay live: the loads
+            __asm__ volatile("" :: "v"(u1.x), "v"(u1.y), "v"(u1.z), "v"(u1.w), "v"(u2.x), "v"(u2.y), "v"(u2.z), "v"(u2.w));   //  and the ray operands are still made)
+            __asm__ volatile("" : "+v"(Wn));
+            return Wn;
+#else
+            rtw_f16v Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a1), b1, zero, 0, 0, 0);
+            Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a2), b2, Wp, 0, 0, 0);
+#ifdef RTW_DUP_MFMA
+#pragma unroll
+            for (int rep = 0; rep < (RTW_DUP_MFMA + 0 > 0 ? RTW_DUP_MFMA + 0 : 1); ++rep) {
+                __asm__ volatile("" : "+v"(Wp));
+                Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a1), b1, zero, 0, 0, 0);
+                Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a2), b2, Wp, 0, 0, 0);
+            }
+#endif
+            return Wp;
+#endif
+        };
         constexpr unsigned HB = 16u / RTW_SCAN_GROUP;       // mask bits per half block
         {
-            rtw_f16v Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[0], zero, 0, 0, 0);
-            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[0], Wv, 0, 0, 0);
-#ifdef RTW_DUP_MFMA      // time probe: the half block's two MFMAs twice (same result)
-            __asm__ volatile("" : "+v"(Wv));
-            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[0], zero, 0, 0, 0);
-            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[0], Wv, 0, 0, 0);
-#endif
+            rtw_f16v Wv = filter_pair(A1, A2, B1[0], B2[0]);
 #ifdef RTW_DUP_EVAL      // time probe: the sign collection twice
             { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
 #endif
@@ -995,13 +1053,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         {
             // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
             // padding at the end), so only one set of A registers is live during the evaluation
-            rtw_f16v Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[1], zero, 0, 0, 0);
-            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[1], Wv, 0, 0, 0);
-#ifdef RTW_DUP_MFMA
-            __asm__ volatile("" : "+v"(Wv));
-            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A1), B1[1], zero, 0, 0, 0);
-            Wv = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, A2), B2[1], Wv, 0, 0, 0);
-#endif
+            rtw_f16v Wv = filter_pair(A1, A2, B1[1], B2[1]);
             __builtin_amdgcn_sched_barrier(0);
             A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];
             __builtin_amdgcn_sched_barrier(0);
@@ -1051,7 +1103,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             if (!act) break;
             if (total + 64u > ws.cap) {
                 clk.lap(4);
-                resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);
+                resolve_pairs<T>(w.numerics, src, o, d, tmin, ws, total, lane, orig);
                 total = 0;
                 clk.lap(5);
             }
@@ -1066,9 +1118,9 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         clk.lap(4);
     }
     if (use_prio) __builtin_amdgcn_s_setprio(sizeof(T) == 4 ? 1 : 0);
-    resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);
+    resolve_pairs<T>(w.numerics, src, o, d, tmin, ws, total, lane, orig);
 #ifdef RTW_DUP_RESOLVE_PAIRS   // instruction/time probe: the final resolve twice (idempotent: min / max of the same keys)
-    resolve_pairs<T>(src, o, d, tmin, ws, total, lane, orig);
+    resolve_pairs<T>(w.numerics, src, o, d, tmin, ws, total, lane, orig);
 #endif
     clk.lap(5);
     int idx;
@@ -1133,6 +1185,7 @@ template <typename T> struct CullScene {
     const float *mf_box;                   //   device order, one binary32 box per block of 32
     int mf_blocks;
     int n_huge, huge[2];                   // huge spheres in this order (see DevScene::huge)
+    int numerics;                          // NUM_* (see DevScene::numerics)
 };
 template <typename T> __host__ __device__ inline MfmaCull mfma_cull_of(const CullScene<T> &c) {
     return MfmaCull{c.mf_ops, c.mf_box, c.mf_blocks, {(float)c.cs[0], (float)c.cs[1], (float)c.cs[2]}, (float)c.rs * 1.000001f + 1e-30f, c.n_huge, {c.huge[0], c.huge[1]}};
@@ -1145,7 +1198,7 @@ __device__ __forceinline__ double t_min(double a, double b) { return __builtin_f
 __device__ __forceinline__ double t_max(double a, double b) { return __builtin_fmax(a, b); }
 
 template <typename T, int STRIDE, typename SRC, typename ORIG>
-__device__ __forceinline__ void resolve_candidates_anyorder(SRC src, ORIG orig, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
+__device__ __forceinline__ void resolve_candidates_anyorder(int num, SRC src, ORIG orig, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
                                                             const unsigned short *list, int cnt) {
     using V4 = typename Vec4<T>::type;
     int i_next = cnt > 0 ? (int)list[0] : 0;
@@ -1157,7 +1210,7 @@ __device__ __forceinline__ void resolve_candidates_anyorder(SRC src, ORIG orig, 
         s_next = src[i_next];
         if (c < cnt) {
             T hb, disc, root;
-            sphere_disc<T>(s.x, s.y, s.z, s.w, o, d, hb, disc);
+            sphere_disc<T>(num, s.x, s.y, s.z, s.w, o, d, hb, disc);
             if (sphere_root<T>(hb, disc, tmin, closest, root)) {       // root in [tmin, closest]
                 bool take = true;
                 if (root == closest && idx >= 0) take = orig[i] > orig[idx];
@@ -1179,7 +1232,7 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
     int idx = -1, cnt = 0;
     auto push = [&](int i) {                       // lane-local: may run in divergent code
         if (cnt >= RTW_LIST_CAP) {
-            resolve_candidates_anyorder<T, STRIDE>(src, orig, o, d, tmin, closest, idx, list, cnt);
+            resolve_candidates_anyorder<T, STRIDE>(w.numerics, src, orig, o, d, tmin, closest, idx, list, cnt);
             cnt = 0;
         }
         list[cnt * STRIDE] = (unsigned short)i;
@@ -1189,7 +1242,7 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
     // spheres entirely behind the ray are not even listed.
     auto member = [&](const V4 &sp, int i) {
         T hb, disc;
-        sphere_disc<T>(sp.x, sp.y, sp.z, sp.w, o, d, hb, disc);
+        sphere_disc<T>(w.numerics, sp.x, sp.y, sp.z, sp.w, o, d, hb, disc);
         if (!(disc < T(0))) { if (!(hb > T(0)) || disc > hb * hb) push(i); }
     };
 
@@ -1277,7 +1330,7 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
         }
         clk.lap(4);
     }
-    resolve_candidates_anyorder<T, STRIDE>(src, orig, o, d, tmin, closest, idx, list, cnt);
+    resolve_candidates_anyorder<T, STRIDE>(w.numerics, src, orig, o, d, tmin, closest, idx, list, cnt);
     clk.lap(5);
     t_hit = closest;
     return idx;

@@ -35,6 +35,15 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// Measurement / test switches of the environment are honoured only under the master switch RTW_ENABLE_TEST_AIDS=1 (read once):
+// without it a stray RTW_SCAN=valu or RTW_JOB_PIXELS=1 in a caller's environment changes nothing (include/rtw_hip.h).
+bool test_aids() {
+    static const bool on = [] { const char *e = getenv("RTW_ENABLE_TEST_AIDS"); return e != nullptr && atoi(e) != 0; }();
+    return on;
+}
+const char *aid_env(const char *name) { return test_aids() ? getenv(name) : nullptr; }
+bool aid_flag(const char *name) { const char *e = aid_env(name); return e != nullptr && atoi(e) != 0; }
+
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -55,7 +64,7 @@ int fail(int code, const char *fmt, ...) {
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
         if (e_ != hipSuccess) {                                                               \
-            static const bool dbg_ = getenv("RTW_DEBUG") != nullptr;                          \
+            static const bool dbg_ = aid_env("RTW_DEBUG") != nullptr;                          \
             if (dbg_) fprintf(stderr, "[rtw debug] %s -> %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
             (void)hipGetLastError();            /* do not leave it for a later hipGetLastError() check */ \
         }                                                                                     \
@@ -401,6 +410,7 @@ rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
     C.kappa = sizeof(T) == 4 ? (T)0.00390625 : (T)2.384185791015625e-07;     // 2^-8 / 2^-22
     C.mf_ops = (const uint4 *)h->c_mf_ops; C.mf_box = (const float *)h->c_mf_box; C.mf_blocks = h->c_mf_blocks;
     C.n_huge = h->c_mf_ops ? h->n_huge : 0; C.huge[0] = h->c_huge[0]; C.huge[1] = h->c_huge[1];
+    C.numerics = rtw::NUM_REFERENCE;
     return C;
 }
 
@@ -586,7 +596,7 @@ int upload_scene(const SceneT *s, int device, rtw_scene_handle *out) {
             h->huge[h->n_huge++] = best;
         }
     }
-    static const bool env_no_huge = getenv("RTW_NO_HUGE") != nullptr && atoi(getenv("RTW_NO_HUGE")) != 0;      // A/B aid
+    static const bool env_no_huge = aid_flag("RTW_NO_HUGE");      // A/B aid
     if (env_no_huge) h->n_huge = 0;
     if (int rc = build_mfma_operands<T>(geom, n, h.get(), &h->mf_ops, &h->mf_blocks, h->n_huge, h->huge)) return rc;
     if (int rc = build_cull<T>(s, h.get())) return rc;
@@ -626,7 +636,8 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
-    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_RAY_POOL | RTW_FLAG_RCCL_REDUCE)) return fail(-2, "unknown flags 0x%x", p->flags);
+    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_RAY_POOL | RTW_FLAG_RCCL_REDUCE | RTW_FLAG_NUMERICS_CONTRACT | RTW_FLAG_NUMERICS_REFERENCE_FMA)) return fail(-2, "unknown flags 0x%x", p->flags);
+    if ((p->flags & RTW_FLAG_NUMERICS_CONTRACT) && (p->flags & RTW_FLAG_NUMERICS_REFERENCE_FMA)) return fail(-2, "RTW_FLAG_NUMERICS_CONTRACT and RTW_FLAG_NUMERICS_REFERENCE_FMA exclude each other");
     // default rule: about 4 samples per chunk, between 16 and 256 chunks (never more than spp):
     // enough items for load balance, few enough stream set-ups (1 sample per chunk costs 7 % at Float64)
     int nch = p->n_chunks > 0 ? p->n_chunks : std::min(p->spp, std::max(16, std::min(256, p->spp / 4)));
@@ -675,20 +686,23 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     }
     C.lens_radius = cam->lens_radius;
     using V4 = typename rtw::Vec4<T>::type;
-    const rtw::DevScene<T> S = dev_scene_of<T>(scene);
+    rtw::DevScene<T> S = dev_scene_of<T>(scene);
+    // the deciding arithmetic of the ray-sphere test (include/rtw_hip.h RTW_FLAG_NUMERICS_*): a property of the render, not of the upload
+    S.numerics = (p->flags & RTW_FLAG_NUMERICS_CONTRACT) ? rtw::NUM_CONTRACT : (p->flags & RTW_FLAG_NUMERICS_REFERENCE_FMA) ? rtw::NUM_REFERENCE_FMA : rtw::NUM_REFERENCE;
 
     // persistent grid: enough 256-thread blocks to fill every CU at the kernel's occupancy
-    static const bool phase_profile = getenv("RTW_PHASE_PROFILE") != nullptr;   // debugging aid, not for timed runs
+    static const bool phase_profile = aid_env("RTW_PHASE_PROFILE") != nullptr;   // debugging aid, not for timed runs
     const size_t list_bytes = (size_t)RTW_LIST_CAP * 256 * sizeof(unsigned short);
     const size_t shared_bytes = (sizeof(rtw::WgShared<T>) + 15) / 16 * 16;
     const bool cull = (p->flags & RTW_FLAG_GROUP_CULL) != 0;
-    const rtw::CullScene<T> CS = cull_scene_of<T>(scene);
+    rtw::CullScene<T> CS = cull_scene_of<T>(scene);
+    CS.numerics = S.numerics;
     const size_t n_cull = (size_t)rtw::cull_exact_count(CS);
     const size_t geom_bytes = cull ? n_cull * sizeof(V4) + ((n_cull * sizeof(unsigned short) + 15) / 16) * 16
                                    : (size_t)rtw::scene_geom_alloc(scene->n, scene->n_pad) * sizeof(V4);
     const bool lds_scene = geom_bytes <= RTW_LDS_SCENE_MAX_BYTES;
     // the plain scan runs pass 1 on the matrix pipe (RTW_SCAN=valu: the all-VALU scan, for A/B measurements)
-    static const bool force_valu = getenv("RTW_SCAN") != nullptr && strcmp(getenv("RTW_SCAN"), "valu") == 0;
+    static const bool force_valu = aid_env("RTW_SCAN") != nullptr && strcmp(aid_env("RTW_SCAN"), "valu") == 0;
     // (group cull: on the matrix pipe too when the scene has the operands; RTW_FLAG_SCAN_VALU selects the all-VALU cull scan)
     const bool mfma = (cull ? scene->c_mf_ops != nullptr : scene->mf_ops != nullptr) && !force_valu && !(p->flags & RTW_FLAG_SCAN_VALU);
     const size_t lds_bytes = list_bytes + shared_bytes + (mfma ? rtw::mfma_cell_bytes<T>() : 0) + (lds_scene ? geom_bytes : 0);
@@ -705,7 +719,7 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     // The ray-pool kernel (rtw_pool.hpp; opt-in: RTW_FLAG_RAY_POOL, or RTW_POOL=1 in the environment for A/B runs): Float32 plain
     // scans on the matrix pipe, when the pool, the rings and the scene copy fit the 160 KB of LDS of a CU (one workgroup of
     // RTW_POOL_W waves per CU); everything else runs the lane-loop kernel above.
-    static const bool env_pool = getenv("RTW_POOL") != nullptr && atoi(getenv("RTW_POOL")) != 0;
+    static const bool env_pool = aid_flag("RTW_POOL");
     size_t pool_lds = 0;
     bool pool = false;
     typedef void (*pool_kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, T *, rtw::DevCounters *);
@@ -736,7 +750,7 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     int job_shift = nch >= 16 ? 2 : 4;
     if (nch >= 64 && n_local * 16 < 150 * grid) job_shift = 0;
     // (measurement aid for A/B runs, tools/gpu_ab.sh: RTW_JOB_PIXELS = 1, 4, 8 or 16; any other value is ignored)
-    static const int env_job_pixels = [] { const char *e = getenv("RTW_JOB_PIXELS"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 4 || v == 8 || v == 16) ? v : 0; }();
+    static const int env_job_pixels = [] { const char *e = aid_env("RTW_JOB_PIXELS"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 4 || v == 8 || v == 16) ? v : 0; }();
     const int job_pixels = p->job_pixels ? p->job_pixels : env_job_pixels;
     if (job_pixels == 16 || job_pixels == 8 || job_pixels == 4 || job_pixels == 1) {
         job_shift = job_pixels == 16 ? 4 : job_pixels == 8 ? 3 : job_pixels == 4 ? 2 : 0;
@@ -752,7 +766,7 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
         return fail(-5, "render too large for one call: %lld pixel-block jobs", total_jobs);
     K.total_jobs = (unsigned)total_jobs; K.local_tiles = (unsigned)n_local; K.bpj = (unsigned)bpj; K.job_shift = (unsigned)job_shift;
     K.rows_shift = (unsigned)std::min(job_shift, 3);       // 4 x 1, 8 x 1, 8 x 2 pixels: whole column strips
-    static const int env_rows_shift = getenv("RTW_ROWS_SHIFT") ? atoi(getenv("RTW_ROWS_SHIFT")) : -1;             // measurement aid: job shape
+    static const int env_rows_shift = aid_env("RTW_ROWS_SHIFT") ? atoi(aid_env("RTW_ROWS_SHIFT")) : -1;             // measurement aid: job shape
     if (env_rows_shift >= 0 && env_rows_shift <= job_shift && env_rows_shift <= 3 && job_shift - env_rows_shift <= 2) K.rows_shift = (unsigned)env_rows_shift;
     K.slot_stride = (unsigned)(sizeof(rtw::JobSlot) + 64u * (1u << job_shift));
     K.n_slots = std::min(24u, (unsigned)RTW_SLOT_BYTES / K.slot_stride);             // 24 / 12 / 7 / 4 slots of 1 / 4 / 8 / 16 pixels
@@ -793,7 +807,7 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
     HIP_TRY(hipEventElapsedTime(&k_ms, r->ev0, r->ev1));
     rtw::DevCounters c;                    // (16 KB incl. the drain histogram)
     HIP_TRY(hipMemcpy(&c, r->ctr, sizeof c, hipMemcpyDeviceToHost));
-    if (getenv("RTW_PHASE_PROFILE") && r->block != 256) {
+    if (aid_env("RTW_PHASE_PROFILE") && r->block != 256) {
         const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(c.end_hist + 256);
         static const char *names[6] = {"SCAN", "LM", "END", "DIEL", "REJ", "WAIT"};
         const double tot = (double)pp[26];
@@ -802,7 +816,7 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
         for (int k = 0; k < 6; ++k)
             fprintf(stderr, "[rtw pool profile]   %-5s batches %10llu  mean fill %5.1f  %5.1f%% of wave-cycles  %7.0f cycles/batch\n", names[k], (unsigned long long)pp[4 * k],
                     pp[4 * k] ? (double)pp[4 * k + 1] / (double)pp[4 * k] : 0.0, 100.0 * (double)pp[4 * k + 2] / tot, pp[4 * k] ? (double)pp[4 * k + 2] / (double)pp[4 * k] : 0.0);
-    } else if (getenv("RTW_PHASE_PROFILE")) {
+    } else if (aid_env("RTW_PHASE_PROFILE")) {
         double tot = 0;
         for (int k = 0; k < 6; ++k) tot += (double)c.phase[k];
         fprintf(stderr, "[rtw phase profile] wave-cycles: pull %.1f%%  sample+scatter finish %.1f%%  scan-pass1/level1 %.1f%%  extract/level2 %.1f%%  resolve %.1f%%  shade %.1f%%  (total %.3g)\n",
@@ -832,7 +846,7 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
         for (int k = 1; k <= 113; ++k) fprintf(stderr, " %u", c.end_hist[k]);
         fprintf(stderr, "\n");
     }
-    if (getenv("RTW_DRAIN_PROFILE") && c.n_waves) {
+    if (aid_env("RTW_DRAIN_PROFILE") && c.n_waves) {
         const double span = (double)(c.t_last - c.t_first) * 1e-5, mean_end = ((double)c.t_end_sum / (double)c.n_waves - (double)c.t_first) * 1e-5;
         fprintf(stderr, "[rtw drain profile] %llu waves: kernel span %.2f ms, mean wave end at %.2f ms -> %.2f ms (%.1f %%) of idle wave slots at the end of the queue\n",
                 (unsigned long long)c.n_waves, span, mean_end, span - mean_end, 100.0 * (span - mean_end) / span);
@@ -875,7 +889,7 @@ int render_device(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
 // buffer + copy into the gather buffer), RTW_DEBUG_NO_PEER=1 forces the host-staged fallback.
 int ensure_peer(const CtxPtr &ctx, int dev, int root, bool *direct) {
     *direct = false;
-    static const bool no_peer = getenv("RTW_DEBUG_NO_PEER") != nullptr && atoi(getenv("RTW_DEBUG_NO_PEER")) != 0;
+    static const bool no_peer = aid_flag("RTW_DEBUG_NO_PEER");
     if (no_peer) return 0;
     if (dev == root) { *direct = true; return 0; }
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1127,7 +1141,7 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
     if (p->flags & RTW_FLAG_COMPACT_TILES) return fail(-2, "n_devices > 1 writes the full frame (RTW_FLAG_COMPACT_TILES is a per-shard layout)");
     const int N = (int)devs.size();
     const bool use_rccl = (p->flags & RTW_FLAG_RCCL_REDUCE) != 0;
-    static const bool dbg_remote = getenv("RTW_DEBUG_REMOTE_SHARDS") != nullptr && atoi(getenv("RTW_DEBUG_REMOTE_SHARDS")) != 0;
+    static const bool dbg_remote = aid_flag("RTW_DEBUG_REMOTE_SHARDS");
     std::vector<ncclComm_t> comms;
     if (use_rccl) { if (int rc = rccl_comms(devs, &comms)) return rc; }
     std::vector<HostLease> L(N);
@@ -1257,8 +1271,10 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
 
 // T0 unit entry point: host slots -> device -> unit_kernel -> host slots
 template <typename T, typename SceneT, typename CamT>
-int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, const CamT *cam) {
-    if (op < 0 || op >= rtw::U_NUM_OPS) return fail(-2, "unknown unit op %d", op);
+int run_unit(int op_arg, int count, const void *in, void *out, const SceneT *scene, const CamT *cam) {
+    const int op = op_arg & 0xff, numerics = (op_arg >> 8) & 3;      // bits 8-9: the numerics mode of the ray-sphere test
+    if (op_arg < 0 || (op_arg >> 10) != 0 || op >= rtw::U_NUM_OPS) return fail(-2, "unknown unit op %d", op_arg);
+    if (numerics > rtw::NUM_REFERENCE_FMA) return fail(-2, "unknown numerics mode %d (unit op %d)", numerics, op_arg);
     if (count < 0 || (count > 0 && (!in || !out))) return fail(-1, "null argument");
     if (count == 0) return 0;
     const bool needs_scene = op == rtw::U_HIT_WORLD || op == rtw::U_RAY_COLOR || op == rtw::U_HIT_WORLD_LDS || op == rtw::U_HIT_WORLD_CULL || op == rtw::U_HIT_WORLD_MFMA || op == rtw::U_HIT_WORLD_MFMA_CULL;
@@ -1279,6 +1295,7 @@ int run_unit(int op, int count, const void *in, void *out, const SceneT *scene, 
         S = dev_scene_of<T>(h_raw);
         CS = cull_scene_of<T>(h_raw);
     }
+    S.numerics = numerics; CS.numerics = numerics;
     ScenePtr h(h_raw);
     HIP_TRY(hipSetDevice(dev));
     rtw::Camera<T> C;

@@ -23,7 +23,7 @@ def _as_image(flat, height, width):
 
 
 def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chunks=0, device=-1, gamma=True,
-           group_cull=False, devices=None, scan_valu=False, ray_pool=False, rccl_reduce=False):
+           group_cull=False, devices=None, scan_valu=False, ray_pool=False, rccl_reduce=False, numerics=None):
     """Render ``scene`` through ``cam``; returns ``img[i, j, :]`` (row i, column j, RGB) of the
     camera's element type, memory-identical to the reference's ``Matrix{RGB{T}}``.
     ``group_cull=True`` selects the opt-in accelerated scan (same image, include/rtw_hip.h);
@@ -31,6 +31,9 @@ def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chun
     ``ray_pool=True`` the ray-pool kernel (RTW_FLAG_RAY_POOL: rays parked in LDS between stages; same image, 14 % slower).
     ``devices``: ``"all"`` or a list of HIP ordinals -- the 8x8 tiles are dealt to those devices
     inside the library (``rtw_params.n_devices/device_ids``); the image is the same for any list.
+    ``numerics``: the deciding arithmetic of ``hit(::Sphere)`` (src/hit.jl:16-18): ``"reference"`` (default: StaticArrays' un-fused
+    dot, one rounding per written operation), ``"reference_fma"`` (the last step contracted) or ``"contract"`` (the three FMA
+    chains of ABI 2); include/rtw_hip.h RTW_FLAG_NUMERICS_*.
     ``rccl_reduce=True`` (with ``devices``): the shards are put together by ONE ncclReduce of zero-padded frames inside the
     library (RTW_FLAG_RCCL_REDUCE) instead of peer copies of compact shards; ``last_stats()["gather_path"]`` says which path ran."""
     if not isinstance(cam, Camera):
@@ -47,7 +50,8 @@ def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chun
     Cm = _capi.make_camera(cam, T)
     P = _capi.make_params(image_width, height, n_samples, depth, seed, n_chunks, 0, 1, device, 1 if gamma else 0,
                            (_capi.FLAG_GROUP_CULL if group_cull else 0) | (_capi.FLAG_SCAN_VALU if scan_valu else 0) |
-                           (_capi.FLAG_RAY_POOL if ray_pool else 0) | (_capi.FLAG_RCCL_REDUCE if rccl_reduce else 0), devices=devices)
+                           (_capi.FLAG_RAY_POOL if ray_pool else 0) | (_capi.FLAG_RCCL_REDUCE if rccl_reduce else 0), devices=devices,
+                           numerics=numerics)
     out = np.empty(height * int(image_width) * 3, dtype=T)
     fn = L.rtw_render_f64 if _capi.is_f64(T) else L.rtw_render_f32
     _capi.check(fn(C.byref(S), C.byref(Cm), C.byref(P), out.ctypes.data_as(C.c_void_p)))
@@ -82,7 +86,7 @@ class DeviceRenderer:
 
     def render_into(self, d_out_ptr, image_width, n_samples, *, depth=16, seed=1, n_chunks=0,
                     shard_index=0, shard_count=1, stream=0, gamma=True, group_cull=False, compact=False,
-                    scan_valu=False, n_elems=None, ray_pool=False, job_pixels=0):
+                    scan_valu=False, n_elems=None, ray_pool=False, job_pixels=0, numerics=None):
         """Enqueue one render into device memory at ``d_out_ptr``: H*W*3 elements, or with
         ``compact=True`` only this shard's tiles (``shard.compact_elems`` elements -- whole 8x8 tiles, which for a ragged
         frame can exceed H*W*3), tile-major.  ``n_elems``: the buffer's length in elements; checked when given."""
@@ -95,7 +99,7 @@ class DeviceRenderer:
         flags = ((_capi.FLAG_GROUP_CULL if group_cull else 0) | (_capi.FLAG_COMPACT_TILES if compact else 0) |
                  (_capi.FLAG_SCAN_VALU if scan_valu else 0) | (_capi.FLAG_RAY_POOL if ray_pool else 0))
         P = _capi.make_params(image_width, height, n_samples, depth, seed, n_chunks, shard_index, shard_count,
-                              -1, 1 if gamma else 0, flags, job_pixels=job_pixels)
+                              -1, 1 if gamma else 0, flags, job_pixels=job_pixels, numerics=numerics)
         fn = self.L.rtw_render_device_f64 if _capi.is_f64(self.T) else self.L.rtw_render_device_f32
         _capi.check(fn(self.handle, C.byref(self.cam), C.byref(P), C.c_void_p(int(d_out_ptr)),
                        C.c_void_p(int(stream))))

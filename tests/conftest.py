@@ -44,17 +44,49 @@ def rtw():
     return rtw_amd
 
 
-def load_golden(name):
-    """-> dict with flat scene, camera dict, params and expected image(s)"""
+#: the numerics modes of the ray-sphere test the device implements (include/rtw_hip.h RTW_FLAG_NUMERICS_*); "reference" is the default
+NUMERICS_MODES = ["reference", "contract", "reference_fma"]
+
+
+def current_numerics():
+    from rtw_amd import _capi
+    return _capi.numerics_name()
+
+
+@pytest.fixture(params=NUMERICS_MODES)
+def numerics(request):
+    """Runs the test once per numerics mode: the mode becomes the default of BOTH sides -- the oracle (render, pixel_samples and
+    the unit-level helpers) and the product's Python mirror (render, DeviceRenderer, the unit ops of test_gpu_units.run_unit) --
+    and load_golden() returns that mode's expected image and counters."""
+    import rtw_oracle
+    from rtw_amd import _capi
+    rtw_oracle.build()
+    prev_o = rtw_oracle.set_numerics(request.param)
+    prev_r = _capi.set_default_numerics(request.param)
+    yield request.param
+    rtw_oracle.set_numerics(prev_o)
+    _capi.set_default_numerics(prev_r)
+
+
+all_numerics = pytest.mark.usefixtures("numerics")
+
+
+def load_golden(name, numerics=None):
+    """-> dict with flat scene, camera dict, params and the expected image(s) / counters of one numerics mode
+    (default: the mode that is current, see the `numerics` fixture)"""
+    mode = numerics or current_numerics()
+    suf = "" if mode == "reference" else "_" + mode
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     flat = {k[len("scene_"):]: z[k] for k in z.files if k.startswith("scene_")}
     flat["n"] = int(flat["n"])
     cam = {k[len("cam_"):]: z[k] for k in z.files if k.startswith("cam_")}
-    out = dict(flat=flat, cam=cam, image=z["image"])
-    for k in ("width", "height", "spp", "depth", "seed", "n_chunks", "segments", "rng_draws"):
+    out = dict(flat=flat, cam=cam, image=z["image" + suf], numerics=mode)
+    for k in ("width", "height", "spp", "depth", "seed", "n_chunks"):
         out[k] = int(z[k])
-    if "image_reference_order" in z.files:
-        out["image_reference_order"] = z["image_reference_order"]
+    for k in ("segments", "rng_draws"):
+        out[k] = int(z[k + suf])
+    if "image_reference_order" + suf in z.files:
+        out["image_reference_order"] = z["image_reference_order" + suf]
     return out
 
 

@@ -1,8 +1,9 @@
 """Tier T1 on the GPU: whole images through the C ABI (rtw_render_f32/_f64 and the
 device-resident variant) against the committed golden vectors and the live oracle.
 
-Tolerance: NONE.  The device and the oracle share one numerics contract (DESIGN.md section 4:
-IEEE ops, no implicit FMA, explicit FMA only in the discriminant, binary64 colour math), the
+Tolerance: NONE.  The device and the oracle share one arithmetic (IEEE ops, one
+rounding per written operation, the ray-sphere discriminant in the selected numerics mode -- the
+reference's own un-fused order by default --, binary64 colour math), the
 same per-(pixel, chunk) Xoroshiro128+ streams and the same exact (order-free) accumulation, so every
 stored channel must be bit-identical (np.array_equal), for Float32 and Float64.  The segment
 counter must match the oracle's exactly as well (every path took the same branches).
@@ -12,7 +13,8 @@ import pytest
 
 from conftest import GOLDEN_CASES, CamObj, load_golden
 
-pytestmark = pytest.mark.gpu
+# every test once per numerics mode of the ray-sphere test (conftest.numerics): oracle, goldens and device switch together
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("numerics")]
 
 
 def gpu_render(g, **over):

@@ -12,7 +12,7 @@ import threading
 import numpy as np
 import pytest
 
-from conftest import CamObj, load_golden
+from conftest import CamObj, all_numerics, load_golden
 from test_gpu_render import gpu_render
 from test_gpu_units import run_unit
 
@@ -33,6 +33,7 @@ def _random_spheres_case(rtw, oracle, T, width, spp, depth=50, n_chunks=0):
 
 
 # ---- Float64 at BASELINE configs[4] geometry -------------------------------------------------------
+@all_numerics
 def test_full_size_f64_4k_properties(oracle, rtw):
     """3840x2160, scene_random_spheres, depth 50, Float64 (configs[4], one GPU's view) at a sample
     count the oracle finishes in seconds: bit-exact vs the live oracle, exact segment count,
@@ -53,6 +54,7 @@ def test_full_size_f64_4k_properties(oracle, rtw):
     assert img[:400].mean() > 0.7 and 0.2 < img[1800:].mean() < 0.8
 
 
+@all_numerics
 def test_f64_more_chunks_than_a_batch(oracle, rtw):
     """Float64, 37 spp in 37 chunks (10 batches per job, the last one ragged), odd image size"""
     T = np.float64
@@ -63,6 +65,7 @@ def test_f64_more_chunks_than_a_batch(oracle, rtw):
 
 
 # ---- multi-device behind the C ABI (n_devices / device_ids; Julia `devices=:all`) -------
+@all_numerics
 @pytest.mark.parametrize("T", [np.float32, np.float64])
 def test_multi_device_render_is_identical(rtw, T):
     import torch
@@ -93,6 +96,7 @@ def test_multi_device_errors(rtw):
         rtw.render(scene, cam, 96, 1, devices="some")
 
 
+@all_numerics
 def test_reentrant_renders_from_two_threads(rtw, oracle):
     """Two host threads render different scenes on the same device at the same time (each call owns
     its counters; there is no shared device workspace): both images and both stats are right."""
@@ -117,6 +121,7 @@ def test_reentrant_renders_from_two_threads(rtw, oracle):
             assert np.array_equal(out[k][0], expect[k][0]) and out[k][1] == expect[k][1], k
 
 
+@all_numerics
 def test_two_streams_in_flight_and_compact_layout(rtw):
     """device-resident path: two renders enqueued back to back on two streams without any host wait;
     the compact tile-major shard layout holds exactly the owned tiles of the full frame"""
@@ -158,6 +163,7 @@ def test_two_streams_in_flight_and_compact_layout(rtw):
     dr.close()
 
 
+@all_numerics
 def test_gather_mode_assembles_the_frame(rtw):
     """shard.render_sharded(mode="gather") on one rank: compact render + indexed copy = the golden frame"""
     import torch
@@ -233,6 +239,7 @@ def test_exact_accumulation_unit(oracle):
         assert (np.isnan(y[i, 0]) and np.isnan(s)) or y[i, 0] == s, (i, y[i, 0], s)
 
 
+@all_numerics
 @pytest.mark.parametrize("name", ["cfg2_random_320x180_64spp_d16_f32", "random_64x36_8spp_d50_f64", "metal4_96x54_8spp_d16_f32"])
 def test_job_size_does_not_change_the_image(name):
     """rtw_params.job_pixels (1, 4, 8 or 16 pixels per work-queue job: column strips of 1x1, 4x1, 8x1, 8x2 rows x columns;
@@ -252,6 +259,7 @@ def test_job_size_does_not_change_the_image(name):
     assert np.array_equal(x, y) and np.array_equal(x, z)
 
 
+@all_numerics
 def test_image_is_invariant_under_chunk_order_and_slots(oracle, rtw):
     """the pixel sum is an exact integer sum: sharding, group-cull and the LDS job-slot schedule
     cannot change it; and a pixel that receives a huge radiance is NaN, as documented"""
@@ -325,6 +333,7 @@ def _stress_rays(rng, flat, m, T, scale):
     return np.concatenate([o, d], 1)
 
 
+@all_numerics
 @pytest.mark.parametrize("T", [np.float32, np.float64])
 def test_scan_stress_plain_lds_and_cull_agree_with_oracle(oracle, T):
     """~10^6 random rays over random scenes (coordinates up to 1e4, |r| from 1e-3 to 1e3, negative
@@ -357,6 +366,7 @@ def test_scan_stress_plain_lds_and_cull_agree_with_oracle(oracle, T):
 
 
 # ---- tier T3: statistical parity with the reference's own sampling order ---------------------------
+@all_numerics
 def test_t3_statistical_parity_with_ref_serial(oracle, rtw):
     """GPU (PIXEL_STREAM streams) vs the oracle in REF_SERIAL mode -- one Xoroshiro128+ per Julia
     thread, static row blocks, serial consumption, reference product order: exactly what

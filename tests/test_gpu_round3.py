@@ -15,7 +15,7 @@ import time
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, all_numerics
 from test_gpu_render import gpu_render
 from test_gpu_round2 import _cam_dict, _random_spheres_case
 from test_gpu_units import run_unit
@@ -65,6 +65,7 @@ def test_bench_refuses_to_time_fewer_gpus_than_asked_for():
     assert p.returncode != 0 and line is None and "WORLD_SIZE=1" in (p.stderr + p.stdout)
 
 
+@all_numerics
 def test_eight_shards_at_1920x1080_sum_to_the_full_frame(rtw):
     """configs[3]'s partition at its real size: 8 shards of 1920x1080 (zero elsewhere) sum to the unsharded frame bit for bit,
     and the compact tile-major shards reassemble to it as well -- what the 8-rank reduce / gather compute."""
@@ -101,6 +102,7 @@ def test_eight_shards_at_1920x1080_sum_to_the_full_frame(rtw):
 
 
 # ---- the filter at full scale ---------------------------------------------------------------------------------------------
+@all_numerics
 def test_three_scan_modes_identical_at_headline_scale(rtw):
     """BASELINE configs[2] in full (1920x1080, 1000 spp, depth 50: 8.2e9 ray segments) in all three scan modes: the
     matrix-pipe filter, the INDEPENDENT all-VALU scan (the contract discriminant for every sphere: no filter, no margin
@@ -125,6 +127,7 @@ def test_three_scan_modes_identical_at_headline_scale(rtw):
     dr.close()
 
 
+@all_numerics
 def test_1080p_32spp_against_the_live_oracle(oracle, rtw):
     """1920x1080 x 32 spp, depth 50, Float32 against the oracle rendered here (6.6e7 samples, 2.6e8 segments): bit-exact image
     and segment count, in the matrix-pipe mode and in the cull mode."""
@@ -250,6 +253,7 @@ def _t3(oracle, g, cam, T, W, H, spp, depth, what):
     assert m2 <= 1.6 * m1, (what, m1, m2)
 
 
+@all_numerics
 def test_t3_float64_random_spheres(oracle, rtw):
     """Tier T3 (tolerances of test_t3_statistical_parity_with_ref_serial) in the reference's own headline precision, Float64:
     GPU PIXEL_STREAM vs the oracle's REF_SERIAL (= `julia -t 180`), scene_random_spheres, 320x180, 1024 spp, depth 16."""
@@ -258,6 +262,7 @@ def test_t3_float64_random_spheres(oracle, rtw):
     _t3(oracle, g, cam, T, 320, 180, 1024, 16, "f64 random spheres")
 
 
+@all_numerics
 def test_t3_dielectric_scene_wide_aperture(oracle, rtw):
     """Tier T3 on the dielectric-heavy scene (scene_diel_spheres: hollow glass, negative radius, total internal reflection)
     through t_cam2 (aperture 2.0: the lens sampler matters), Float32, 320x180, 1024 spp, depth 16."""
@@ -326,6 +331,7 @@ def test_host_entry_point_reuses_its_context(rtw):
 
 
 # ---- job queues: frames that fill the eight queues very unevenly, and the size limit ------------------------------------
+@all_numerics
 @pytest.mark.parametrize("W,H", [(8, 2048), (24, 1000), (2048, 8), (72, 9)])
 def test_narrow_and_flat_frames(oracle, rtw, W, H):
     """Tile column tj belongs to job queue tj mod 8 (claim_job): an 8-pixel-wide frame has ONE non-empty queue, a 24-pixel-wide one

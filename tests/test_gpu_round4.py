@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, ROOT, load_golden
+from conftest import GOLDEN_CASES, ROOT, all_numerics, load_golden
 from test_gpu_render import gpu_render
 from test_gpu_round2 import _random_spheres_case
 
@@ -20,6 +20,7 @@ FLAG_CULL, FLAG_COMPACT, FLAG_VALU, FLAG_POOL = 1, 2, 4, 8
 
 
 # ---- the ray-pool kernel -------------------------------------------------------------------------------------------------
+@all_numerics
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_ray_pool_matches_golden_bit_exact(name):
     """RTW_FLAG_RAY_POOL: rays parked in LDS between the stages, every stage on full waves of one kind (Float32; a Float64
@@ -31,6 +32,7 @@ def test_ray_pool_matches_golden_bit_exact(name):
     assert st.block_threads == (1024 if g["image"].dtype == np.float32 else 256)
 
 
+@all_numerics
 @pytest.mark.parametrize("W,H", [(8, 2048), (24, 1000), (2048, 8), (72, 9), (1, 1), (9, 7)])
 def test_ray_pool_ragged_frames(oracle, rtw, W, H):
     """frames that are not whole tiles, one-pixel frames, frames with fewer items than the pool has slots"""
@@ -43,6 +45,7 @@ def test_ray_pool_ragged_frames(oracle, rtw, W, H):
     assert np.array_equal(img, ref) and st.segments == ost["segments"]
 
 
+@all_numerics
 @pytest.mark.parametrize("job_pixels", [1, 4, 8, 16])
 @pytest.mark.parametrize("spp,n_chunks", [(3, 0), (40, 0), (97, 0), (64, 1), (200, 200)])
 def test_ray_pool_job_shapes_and_chunkings(job_pixels, spp, n_chunks):
@@ -56,6 +59,7 @@ def test_ray_pool_job_shapes_and_chunkings(job_pixels, spp, n_chunks):
     assert np.array_equal(a, b) and sa.segments == sb.segments and sa.samples == sb.samples == 160 * 90 * spp
 
 
+@all_numerics
 def test_ray_pool_depth_zero_and_one(oracle, rtw):
     """max_depth 0: every path is over before its first scan (the draws of the camera ray are still consumed); 1: one bounce"""
     T = np.float32
@@ -66,6 +70,7 @@ def test_ray_pool_depth_zero_and_one(oracle, rtw):
         assert np.array_equal(img, ref) and st.segments == ost["segments"], depth
 
 
+@all_numerics
 def test_ray_pool_shards_and_compact_tiles(rtw):
     """3 shards, full-frame and compact: the pool kernel's shards sum / scatter to the unsharded lane-loop frame"""
     import torch
@@ -95,6 +100,7 @@ def test_ray_pool_shards_and_compact_tiles(rtw):
     dr.close()
 
 
+@all_numerics
 def test_ray_pool_identical_at_1080p(rtw):
     """1920x1080 x 100 spp, depth 50 (8.2e8 segments): pool kernel == lane-loop kernel, image and counters"""
     import torch
@@ -115,6 +121,7 @@ def test_ray_pool_identical_at_1080p(rtw):
 
 
 # ---- Float64 at full scale --------------------------------------------------------------------------------------------------
+@all_numerics
 def test_three_scan_modes_identical_f64_4k(rtw):
     """BASELINE configs[4]'s geometry -- 3840x2160, Float64, depth 50 -- at 100 spp (3.3e9 ray segments) in all three scan modes.  The
     Float64 kernel feeds the SAME binary32 / f16 matrix-pipe filter with inputs ROUNDED from binary64 (an extra 1.5 S term of its error
@@ -139,6 +146,7 @@ def test_three_scan_modes_identical_f64_4k(rtw):
     dr.close()
 
 
+@all_numerics
 def test_f64_4k_8spp_against_the_live_oracle(oracle, rtw):
     """3840x2160 x 8 spp, depth 50, Float64 (6.6e7 samples, 1.8e8 segments) against the oracle rendered here: bit-exact image and
     segment count, plain and cull mode (round 2 compared this geometry at 1 spp)."""
@@ -151,6 +159,7 @@ def test_f64_4k_8spp_against_the_live_oracle(oracle, rtw):
         assert np.array_equal(img, ref), int((img != ref).sum())
 
 
+@all_numerics
 def test_f64_published_configuration_modes_identical(rtw):
     """the reference's published configuration (Float64, 1920x1080, depth 16; README.md:86) at 200 spp: three scan modes, one image"""
     import torch
@@ -204,15 +213,15 @@ def _probe(spec, env_extra=None):
 
 def test_gather_branches_on_one_device():
     """The branches of the in-library multi-device gather that a one-GPU box cannot reach by itself, forced by the test aids of
-    rtw_hip.hip: RTW_DEBUG_REMOTE_SHARDS=1 makes every shard but the first render into its own buffer and COPY it into the gather
+    the library (RTW_ENABLE_TEST_AIDS=1): RTW_DEBUG_REMOTE_SHARDS=1 makes every shard but the first render into its own buffer and COPY it into the gather
     buffer (hipMemcpyPeerAsync, the cross-device branch); with RTW_DEBUG_NO_PEER=1 the copy takes the host-staged fallback (pinned
     staging, D2H + H2D) that a platform without peer access gets.  Same frame as one device, and rtw_stats_t.gather_path says which ran."""
     one = _probe({"one": {}})["one"]
     same = _probe({"x": {"devices": [0, 0, 0]}})["x"]
     assert same["sha"] == one["sha"] and same["gather_path"] == 8 and same["segments"] == one["segments"]          # RTW_GATHER_SAME_DEVICE
-    peer = _probe({"x": {"devices": [0, 0, 0]}}, {"RTW_DEBUG_REMOTE_SHARDS": "1"})["x"]
+    peer = _probe({"x": {"devices": [0, 0, 0]}}, {"RTW_ENABLE_TEST_AIDS": "1", "RTW_DEBUG_REMOTE_SHARDS": "1"})["x"]
     assert peer["sha"] == one["sha"] and peer["gather_path"] == 1                                                # RTW_GATHER_PEER
-    staged = _probe({"x": {"devices": [0, 0, 0, 0, 0]}}, {"RTW_DEBUG_REMOTE_SHARDS": "1", "RTW_DEBUG_NO_PEER": "1"})["x"]
+    staged = _probe({"x": {"devices": [0, 0, 0, 0, 0]}}, {"RTW_ENABLE_TEST_AIDS": "1", "RTW_DEBUG_REMOTE_SHARDS": "1", "RTW_DEBUG_NO_PEER": "1"})["x"]
     assert staged["sha"] == one["sha"] and staged["gather_path"] == 2                                            # RTW_GATHER_HOST_STAGED
 
 
@@ -260,6 +269,7 @@ def test_multi_gpu_bench_rccl_matches_one_rank(collective):
 
 
 # ---- huge spheres tested in-lane (DevScene::huge) -------------------------------------------------------------------------------
+@all_numerics
 @pytest.mark.parametrize("T", [np.float32, np.float64])
 @pytest.mark.parametrize("layout", ["one", "two_coincident", "two_nested_negative", "three", "first_and_last"])
 def test_huge_spheres_in_lane(oracle, T, layout):
@@ -297,9 +307,9 @@ def test_huge_spheres_in_lane(oracle, T, layout):
 
 
 def test_huge_sphere_path_off_gives_the_same_frame():
-    """RTW_NO_HUGE=1 (A/B aid, read at scene upload) sends every sphere through the filter again: same frame, same counters"""
+    """RTW_NO_HUGE=1 (A/B aid, read at scene upload; like every aid only under RTW_ENABLE_TEST_AIDS=1) sends every sphere through the filter again: same frame, same counters"""
     on = _probe({"x": {}})["x"]
-    off = _probe({"x": {}}, {"RTW_NO_HUGE": "1"})["x"]
+    off = _probe({"x": {}}, {"RTW_ENABLE_TEST_AIDS": "1", "RTW_NO_HUGE": "1"})["x"]
     assert on["sha"] == off["sha"] and on["segments"] == off["segments"]
 
 

@@ -21,7 +21,8 @@ import pytest
 
 from conftest import CamObj, load_golden
 
-pytestmark = pytest.mark.gpu
+# every test once per numerics mode of the ray-sphere test (conftest.numerics): oracle and device switch together
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("numerics")]
 F = [np.float32, np.float64]
 
 
@@ -36,7 +37,7 @@ def run_unit(op, x, n_out, T, flat=None, cam=None):
     if cam is not None:
         Cm = _capi.make_camera(cam, T)
     fn = L.rtw_unit_f64 if T is np.float64 else L.rtw_unit_f32
-    _capi.check(fn(op, x.shape[0], x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+    _capi.check(fn(op | _capi.numerics_unit_bits(), x.shape[0], x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
                    C.byref(S) if S is not None else None, C.byref(Cm) if Cm is not None else None))
     return y
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(rtw):
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rtw_abi_version() == 2
+    assert L.rtw_abi_version() == _capi.ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header(rtw):
@@ -46,8 +46,9 @@ def test_flag_constants_match_header(rtw):
     header = open(os.path.join(ROOT, "include", "rtw_hip.h")).read()
     flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+RTW_FLAG_([A-Z_]+)\s+(\d+)", header)}
     assert flags == {"GROUP_CULL": _capi.FLAG_GROUP_CULL, "COMPACT_TILES": _capi.FLAG_COMPACT_TILES, "SCAN_VALU": _capi.FLAG_SCAN_VALU,
-                     "RAY_POOL": _capi.FLAG_RAY_POOL, "RCCL_REDUCE": _capi.FLAG_RCCL_REDUCE}
-    assert sorted(flags.values()) == [1, 2, 4, 8, 16]
+                     "RAY_POOL": _capi.FLAG_RAY_POOL, "RCCL_REDUCE": _capi.FLAG_RCCL_REDUCE,
+                     "NUMERICS_CONTRACT": _capi.FLAG_NUMERICS_CONTRACT, "NUMERICS_REFERENCE_FMA": _capi.FLAG_NUMERICS_REFERENCE_FMA}
+    assert sorted(flags.values()) == [1, 2, 4, 8, 16, 32, 64]
     jl = open(os.path.join(ROOT, "julia", "RTWeekendHIP.jl")).read()
     assert "(group_cull ? 1 : 0) | (scan_valu ? 4 : 0) | (ray_pool ? 8 : 0) | (rccl_reduce ? 16 : 0)" in jl
 
@@ -157,7 +158,8 @@ def test_julia_shim_struct_layouts_match_the_c_abi():
         cf = [(n, getattr(ct, n).offset, getattr(ct, n).size) for n, _ in ct._fields_]
         assert [(o, s) for _, o, s in lay] == [(o, s) for _, o, s in cf], (jl, lay, cf)
         assert [n for n, _, _ in lay] == [n for n, _, _ in cf], jl
-    assert "v == 2 ||" in src and _capi.ABI_VERSION == 2
+    assert "v == 3 ||" in src and _capi.ABI_VERSION == 3
+    assert "numerics === :contract ? 32 : numerics === :reference_fma ? 64 : 0" in src            # the flag bits of include/rtw_hip.h
 
 
 def test_check_julia_kat_detects_a_wrong_assumption(tmp_path):

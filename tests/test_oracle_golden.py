@@ -3,9 +3,10 @@ mode cross-checks, and the host mirror vs the oracle's mirror of the producers. 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, load_golden
+from conftest import GOLDEN_CASES, all_numerics, load_golden
 
 
+@all_numerics
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_oracle_reproduces_golden(oracle, name):
     g = load_golden(name)
@@ -16,6 +17,7 @@ def test_oracle_reproduces_golden(oracle, name):
     assert st["segments"] == g["segments"] and st["rng_draws"] == g["rng_draws"]
 
 
+@all_numerics
 @pytest.mark.parametrize("name", [c for c in GOLDEN_CASES if "cfg2" not in c])
 def test_forward_product_matches_reference_order(name):
     """The device multiplies attenuations front to back; the reference multiplies them as the
@@ -106,3 +108,60 @@ def test_random_scene_composition(rtw):
     rtw.reseed()
     s2 = rtw.scene_random_spheres(elem_type=np.float32)
     assert len(s2) == len(s) and all(np.array_equal(a.center, b.center) for a, b in zip(s, s2))
+
+
+def test_numerics_modes_of_the_ray_sphere_test(oracle, rtw):
+    """src/hit.jl:16-18 in the four evaluations an LLVM build could produce (rtw_oracle.h "NUMERICS MODES").  In Float32 the choice is
+    NOT noise: the r = 1000 ground sphere of scene_random_spheres turns the last-bit differences of the discriminant into tmin
+    re-hits (each multiplies the path by albedo 0.5): the reference's own un-fused order traces ~4 % more ray segments per sample than
+    the three-FMA contract form of rounds 1-4 and its image is darker by ~0.003 in the mean.  Float64: the same streams give images
+    with the same mean and segment counts within 0.1 %."""
+    T = np.float32
+    rtw.reseed()
+    flat = rtw.flatten_scene(rtw.scene_random_spheres(elem_type=T), T)
+    cam = rtw.t_cam1(elem_type=T)
+    res = {}
+    for mode in ("reference", "contract", "reference_fma", "reference_fma2"):
+        img, st = oracle.render(flat, cam, 160, 90, 8, T=T, max_depth=50, seed=1, numerics=mode)
+        res[mode] = (img.astype(np.float64), st["segments"] / st["samples"])
+    sps = {m: v[1] for m, v in res.items()}
+    assert 1.03 < sps["reference"] / sps["contract"] < 1.06, sps
+    assert sps["contract"] < sps["reference_fma"] < sps["reference"] and abs(sps["reference_fma2"] - sps["reference_fma"]) < 0.01, sps
+    assert 0.001 < res["contract"][0].mean() - res["reference"][0].mean() < 0.006                 # the contract image is brighter
+    assert not np.array_equal(res["reference"][0], res["reference_fma"][0])
+    # the default is the reference's own order, and the unit-level exports follow set_numerics
+    assert oracle.numerics_code(None) == oracle.NUMERICS_REFERENCE
+    img0, _ = oracle.render(flat, cam, 160, 90, 8, T=T, max_depth=50, seed=1)
+    assert np.array_equal(img0.astype(np.float64), res["reference"][0])
+    T = np.float64
+    rtw.reseed()
+    flat = rtw.flatten_scene(rtw.scene_random_spheres(elem_type=T), T)
+    cam = rtw.t_cam1(elem_type=T)
+    a, sa = oracle.render(flat, cam, 160, 90, 8, T=T, max_depth=50, seed=1, numerics="reference")
+    b, sb = oracle.render(flat, cam, 160, 90, 8, T=T, max_depth=50, seed=1, numerics="contract")
+    assert abs(sa["segments"] - sb["segments"]) <= 1e-3 * sa["segments"]
+    assert abs(a.mean() - b.mean()) < 1e-3            # (last-bit differences still send individual paths elsewhere: not bit-equal)
+
+
+def test_hit_sphere_numerics_kat(oracle):
+    """A ray whose discriminant's sign depends on the evaluation order: built by search, then pinned.  oc = (3, 4, 12)-ish vectors where
+    half_b^2 and c agree to the last bits, so fma(half_b, half_b, -c) and half_b*half_b - c round differently."""
+    T = np.float32
+    rng = np.random.default_rng(12)
+    found = {}
+    for _ in range(200000):
+        c = rng.uniform(-1, 1, 3).astype(T)
+        d = rng.normal(size=3); d = (d / np.linalg.norm(d)).astype(T)
+        # origin on a tangent line at distance ~r: grazing
+        r = T(0.5)
+        n = np.cross(d.astype(np.float64), rng.normal(size=3)); n /= np.linalg.norm(n)
+        o = (c.astype(np.float64) + n * (0.5 + rng.uniform(-3e-8, 3e-8)) - d.astype(np.float64) * rng.uniform(1, 3)).astype(T)
+        hits = []
+        for mode in ("reference", "contract", "reference_fma"):
+            with oracle.numerics(mode):
+                hits.append(oracle.hit_sphere(c, r, o, d, T(1e-4), np.inf, T) is not None)
+        if len(set(hits)) > 1:
+            found[tuple(hits)] = (c, o, d)
+            if len(found) >= 2:
+                break
+    assert found, "no ray separates the numerics modes: the modes are not wired through hit_sphere"

@@ -13,7 +13,7 @@ for round in 1 2; do
   for spec in "$@"; do
     name=${spec%%=*}
     if [ -n "$DRAIN" ]; then
-      echo "$name: $(RTW_HIP_LIB=/tmp/librtw_$name.so RTW_DRAIN_PROFILE=1 timeout ${AB_TIMEOUT:-300} python tools/gpu_quick.py ${DT:-f32} 1920 ${SPP:-1000} 50 plain 2 2>&1 | grep -E "drain profile\] [0-9]+ waves" | tail -1 | sed 's/.*kernel span/span/')"
+      echo "$name: $(RTW_HIP_LIB=/tmp/librtw_$name.so RTW_ENABLE_TEST_AIDS=1 RTW_DRAIN_PROFILE=1 timeout ${AB_TIMEOUT:-300} python tools/gpu_quick.py ${DT:-f32} 1920 ${SPP:-1000} 50 plain 2 2>&1 | grep -E "drain profile\] [0-9]+ waves" | tail -1 | sed 's/.*kernel span/span/')"
     else
       echo "$name: $(RTW_HIP_LIB=/tmp/librtw_$name.so timeout ${AB_TIMEOUT:-300} python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $BENCH_ARGS 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'Msamples/s  frac', d['roofline']['frac'], 'kernel_ms', d['roofline']['kernel_ms'])")"
     fi

@@ -9,7 +9,7 @@ done
 for spec in "$@"; do
   name=${spec%%=*}
   if [ -n "$PROF" ]; then
-    echo "== $name"; RTW_PHASE_PROFILE=1 RTW_HIP_LIB=/tmp/librtw_$name.so timeout 200 python tools/gpu_quick.py f32 1920 ${SPP:-300} 50 ${MODE:-pool} 1 2>&1 | grep -E "pool profile|kernel"
+    echo "== $name"; RTW_ENABLE_TEST_AIDS=1 RTW_PHASE_PROFILE=1 RTW_HIP_LIB=/tmp/librtw_$name.so timeout 200 python tools/gpu_quick.py f32 1920 ${SPP:-300} 50 ${MODE:-pool} 1 2>&1 | grep -E "pool profile|kernel"
   else
     echo "$name: $(RTW_HIP_LIB=/tmp/librtw_$name.so timeout 200 python tools/gpu_quick.py f32 1920 ${SPP:-300} 50 ${MODE:-pool} 2 2>&1 | grep kernel | tail -1 | sed 's/.*cull False: //; s/segs.*//')"
   fi

@@ -58,4 +58,4 @@ PY
 cat $O/ubench_write_size.txt
 bash tools/gpu_probe_phases.sh base mfma eval extract resolve reject noskip rejcap3 rejcap2 cmp 2>&1 | grep -v amdgpu.ids > $O/probe_phases.txt; cat $O/probe_phases.txt
 # the ray-pool kernel's own stage profile (batches, fill, wave-cycles per stage) next to the lane loop's phase profile
-(RTW_PHASE_PROFILE=1 python tools/gpu_quick.py f32 1920 1000 50 pool 1; RTW_PHASE_PROFILE=1 python tools/gpu_quick.py f32 1920 1000 50 plain 1) 2>&1 | grep -E "profile\]|kernel" > $O/pool_stage_profile.txt; cat $O/pool_stage_profile.txt
+(RTW_ENABLE_TEST_AIDS=1 RTW_PHASE_PROFILE=1 python tools/gpu_quick.py f32 1920 1000 50 pool 1; RTW_ENABLE_TEST_AIDS=1 RTW_PHASE_PROFILE=1 python tools/gpu_quick.py f32 1920 1000 50 plain 1) 2>&1 | grep -E "profile\]|kernel" > $O/pool_stage_profile.txt; cat $O/pool_stage_profile.txt

@@ -19,6 +19,7 @@ import rtw_amd as R          # noqa: E402  (host mirror: scene / camera producer
 import rtw_oracle as O       # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
+MODES = ("reference", "contract", "reference_fma")       # what the device implements (the oracle also has reference_fma2)
 
 
 def cam_dict(cam):
@@ -30,16 +31,25 @@ def cam_dict(cam):
 def case(name, flat, cam, width, spp, depth, T, seed=1, n_chunks=0, both_orders=True):
     height = R.image_height(width)
     nch = n_chunks or O.default_n_chunks(spp)
-    img, st = O.render(flat, cam, width, height, spp, T=T, max_depth=depth, seed=seed, n_chunks=nch,
-                       product_order=O.PRODUCT_FORWARD)
     d = {"scene_" + k: np.asarray(v) for k, v in flat.items()}
     d.update(cam_dict(cam))
-    d.update(width=width, height=height, spp=spp, depth=depth, seed=seed, n_chunks=nch,
-             image=np.ascontiguousarray(img), segments=st["segments"], rng_draws=st["rng_draws"])
-    if both_orders:
-        img_ref, _ = O.render(flat, cam, width, height, spp, T=T, max_depth=depth, seed=seed, n_chunks=nch,
-                              product_order=O.PRODUCT_REFERENCE)
-        d["image_reference_order"] = np.ascontiguousarray(img_ref)
+    d.update(width=width, height=height, spp=spp, depth=depth, seed=seed, n_chunks=nch)
+    # one expected image + counters per numerics mode of the ray-sphere test (include/rtw_hip.h RTW_FLAG_NUMERICS_*):
+    # "reference" (the default) under the plain keys, the others with the mode's name as a suffix
+    for mode in MODES:
+        suf = "" if mode == "reference" else "_" + mode
+        img, st = O.render(flat, cam, width, height, spp, T=T, max_depth=depth, seed=seed, n_chunks=nch,
+                           product_order=O.PRODUCT_FORWARD, numerics=mode)
+        d["image" + suf] = np.ascontiguousarray(img)
+        d["segments" + suf] = st["segments"]
+        d["rng_draws" + suf] = st["rng_draws"]
+        if mode == "reference":
+            img0, st0 = img, st
+        if both_orders:
+            img_ref, _ = O.render(flat, cam, width, height, spp, T=T, max_depth=depth, seed=seed, n_chunks=nch,
+                                  product_order=O.PRODUCT_REFERENCE, numerics=mode)
+            d["image_reference_order" + suf] = np.ascontiguousarray(img_ref)
+    img, st = img0, st0
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **d)
     print(f"{name}: {img.shape} {img.dtype} segments={st['segments']} -> {os.path.getsize(path)/1024:.0f} KiB")
