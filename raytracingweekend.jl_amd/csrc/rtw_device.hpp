@@ -1029,8 +1029,12 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
 #ifdef RTW_DUP_MFMA
 #pragma unroll
             for (int rep = 0; rep < (RTW_DUP_MFMA + 0 > 0 ? RTW_DUP_MFMA + 0 : 1); ++rep) {
+                // (the repeated pair takes its sphere operand through an opaque copy and starts from the previous result x 0: left
+                //  as the same expression it is merged with the first pair -- rounds 3 and 4 measured 16 register copies, not MFMAs)
+                uint4 a1c = a1;
+                __asm__ volatile("" : "+v"(a1c.x), "+v"(a1c.y), "+v"(a1c.z), "+v"(a1c.w));
                 __asm__ volatile("" : "+v"(Wp));
-                Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a1), b1, zero, 0, 0, 0);
+                Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a1c), b1, zero, 0, 0, 0);
                 Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a2), b2, Wp, 0, 0, 0);
             }
 #endif

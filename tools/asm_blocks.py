@@ -2,7 +2,7 @@
 """Static instruction counts per basic block of one kernel in build/asm/*.s (make -C raytracingweekend.jl_amd/csrc asm).
 usage: python tools/asm_blocks.py <kernel name substring> [min instructions per block to list]"""
 import re, sys
-s = open('/root/repo/build/asm/rtw_hip-hip-amdgcn-amd-amdhsa-gfx950.s').read()
+s = open('/root/repo/build/asm/rtw_launch-hip-amdgcn-amd-amdhsa-gfx950.s').read()
 pat = sys.argv[1]; thr = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 m = [x for x in re.finditer(r'^(_Z\S*):\s*(;.*)?$', s, re.M) if pat in x.group(1)][0]
 print(m.group(1))

@@ -3,7 +3,7 @@
 usage: python tools/kernel_resources.py [extra hipcc flags]   (cross-compiles for gfx950, no GPU needed)"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "raytracingweekend.jl_amd", "csrc", "rtw_hip.hip")
+src = os.path.join(ROOT, "raytracingweekend.jl_amd", "csrc", "rtw_launch.hip")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form",
        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
