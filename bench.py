@@ -53,8 +53,14 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   f64_4k       -- configs[4]'s single-GPU share (3840x2160, Float64), with its own roofline and cpu_baseline.
   f64_1080p_d16 -- the reference's PUBLISHED configuration (Float64, 1920x1080, 1000 spp, depth 16: README.md:86,118-119,
                   1.617 Msamples/s on a Ryzen 3700 -- different hardware), with its own roofline, cpu_baseline and `vs_published`.
-  N > 1        -- `render_ms_max` / `render_ms_min` (per-rank kernel time, mean over the steps) and `collective_ms` (HIP events around
-                  the one collective on rank 0's stream, mean over the steps): a bad scaling point can be attributed.
+  N > 1        -- `render_ms_max` / `render_ms_min` (per-rank kernel time, mean over the steps) and `collective_ms` (HIP events on rank 0's
+                  stream from the end of ITS render to the end of the one collective, mean over the steps: the collective itself PLUS the wait
+                  for the slowest rank's render, i.e. about render_ms_max - render_ms(rank 0) more than the transfer): a bad scaling point can be attributed.
+  numerics_legs -- the same workload in the other numerics modes of the ray-sphere test (`--numerics`, include/rtw_hip.h RTW_FLAG_NUMERICS_*):
+                  DIFFERENT images by design (Float32: the contract form traces ~4 % fewer segments per sample); each with its segments per sample.
+  in_library_devices -- rtw_render_* on host buffers with a device LIST (what a Julia caller gets with `devices=...`): gather by peer copies and
+                  by the in-library RCCL reduce, per-device kernel ms, end-to-end ms, gather_path, frame hash.  On a one-GPU box the list repeats
+                  ordinal 0 (peer) / holds it once (RCCL, one rank) and the leg says `emulation: true`; `--in-library-devices N` runs only this leg.
 """
 import argparse
 import hashlib
@@ -102,6 +108,12 @@ def parse_args(argv=None):
     ap.add_argument("--ray-pool", action="store_true", help="time the opt-in ray-pool kernel (RTW_FLAG_RAY_POOL) instead of the lane-loop kernel")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes that measure roofline.traffic / issue_busy in this run")
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per pixel (0 = library default rule)")
+    ap.add_argument("--numerics", choices=["reference", "contract", "reference_fma"], default="reference",
+                    help="the deciding arithmetic of the ray-sphere test (include/rtw_hip.h RTW_FLAG_NUMERICS_*): reference = src/hit.jl:16-18 as the reference "
+                         "evaluates it (the default of the library); the default run also times the other two as `numerics_legs`")
+    ap.add_argument("--in-library-devices", type=int, default=0, metavar="N",
+                    help="time ONLY the in-library device list (what a Julia caller gets with devices=...): rtw_render_* on host buffers with N devices, "
+                         "gathered by peer copies and by the in-library RCCL reduce; N > the visible devices: ordinals repeat (emulation, labelled so)")
     ap.add_argument("--emulate-shard-of", type=int, default=0,
                     help="analysis only: on ONE GPU render shard 0 of N (what each rank of an N-GPU run does)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration per leg")
@@ -207,7 +219,7 @@ class Workload:
         self.renderer.close()
         self.fb = None
 
-    def timed(self, n_steps, n_warm, *, cull, depth, record=None, valu=False, coll_ms=None, pool=None):
+    def timed(self, n_steps, n_warm, *, cull, depth, record=None, valu=False, coll_ms=None, pool=None, numerics=None):
         """n_warm untimed + n_steps timed steps bracketed by barrier + synchronize; returns max-over-ranks seconds.
         `coll_ms` (a list): per timed step, the HIP-event time between the end of this rank's render and the end of the collective."""
         c, a = self.c, self.c.args
@@ -222,7 +234,7 @@ class Workload:
                 self.renderer.render_into(self.fb.data_ptr(), self.W, self.spp, depth=depth, seed=1, n_chunks=a.chunks, shard_index=idx,
                                           shard_count=cnt, stream=c.stream.cuda_stream, group_cull=cull,
                                           compact=a.collective == "gather", scan_valu=valu and not cull, n_elems=self.fb.numel(),
-                                          ray_pool=pool and not cull and not valu)
+                                          ray_pool=pool and not cull and not valu, numerics=numerics or a.numerics)
                 return self.fb
             hook = None
             if timed_step and coll_ms is not None and c.world > 1:
@@ -258,7 +270,7 @@ class Workload:
 
         def call():
             c.R.render(self.scene, self.cam, self.W, self.spp, depth=depth, seed=1, n_chunks=a.chunks, device=c.local_rank,
-                       group_cull=cull, scan_valu=valu and not cull, ray_pool=a.ray_pool and not cull and not valu)
+                       group_cull=cull, scan_valu=valu and not cull, ray_pool=a.ray_pool and not cull and not valu, numerics=a.numerics)
             k_ms.append(c.R.last_stats()["kernel_ms"])
         t = time.perf_counter()
         call()                                                  # the first call of a scene builds the library's per-device context
@@ -315,7 +327,8 @@ def roofline_of(wl, k_s, tests_per_launch, seg_per_sample, *, cull, valu, world,
     vpeak = VALU_PEAK_TFLOPS[wl.dtype]
     issue = None
     if matrix:
-        issue = {"model": True, "what": "a SIMD issues EITHER a 32-cycle v_mfma_f32_32x32x16_f16 or a VALU instruction (no overlap on gfx950: tools/ubench_mfma_pipe.hip); "
+        issue = {"model": True, "what": "a SIMD issues EITHER a 32-cycle v_mfma_f32_32x32x16_f16 or a VALU instruction (no overlap on gfx950: tools/ubench_mfma_pipe.hip, and in the kernel itself "
+                                        "profiles/r05_probe_phases.txt: every MFMA executed twice / three times costs +38 % / +80 %, the kernel without them runs 19 % faster per wave-segment); "
                                         "per 64 tests 4 MFMA cycles + one v_alignbit_b32"}
         for name, cyc in ALIGNBIT_CYCLES.items():
             pk = N_SIMD * CLOCK_HZ / (MFMA_CYCLES_PER_64_TESTS + cyc) * 64 * FLOP_PER_TEST / 1e12
@@ -358,7 +371,7 @@ def roofline_of(wl, k_s, tests_per_launch, seg_per_sample, *, cull, valu, world,
     }
 
 
-def live_pmc(dtype, width, spp, depth, timeout_s=90):
+def live_pmc(dtype, width, spp, depth, numerics="reference", timeout_s=90):
     """HBM traffic and issue-busy of ONE launch of this workload, measured in this run: three `rocprofv3 --pmc` passes of this script
     itself (`--steps 1 --warmup 0 --no-extras`: exactly one trace-kernel launch each; FETCH_SIZE and WRITE_SIZE in separate passes, as
     MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled: its gfx950 correction; KiB units).  Returns None when rocprofv3 is not there, a
@@ -369,7 +382,7 @@ def live_pmc(dtype, width, spp, depth, timeout_s=90):
         return None
     base = tempfile.mkdtemp(prefix="rtw_pmc_", dir="/tmp")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--dtype", dtype,
-           "--width", str(width), "--spp", str(spp), "--depth", str(depth)]
+           "--width", str(width), "--spp", str(spp), "--depth", str(depth), "--numerics", numerics]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -416,11 +429,11 @@ def cpu_legs(wl, seconds):
 
     def leg(nthr):
         t = time.perf_counter()
-        O.render(flat, wl.cam, wl.W, wl.H, 1, T=wl.T, max_depth=wl.depth, seed=1, n_chunks=1, omp_threads=nthr)
+        O.render(flat, wl.cam, wl.W, wl.H, 1, T=wl.T, max_depth=wl.depth, seed=1, n_chunks=1, omp_threads=nthr, numerics=wl.c.args.numerics)
         t1 = time.perf_counter() - t
         s_spp = int(max(1, min(64, round(seconds / max(t1, 1e-3)))))
         t = time.perf_counter()
-        O.render(flat, wl.cam, wl.W, wl.H, s_spp, T=wl.T, max_depth=wl.depth, seed=1, omp_threads=nthr)
+        O.render(flat, wl.cam, wl.W, wl.H, s_spp, T=wl.T, max_depth=wl.depth, seed=1, omp_threads=nthr, numerics=wl.c.args.numerics)
         tc = time.perf_counter() - t
         return {"value": round(wl.W * wl.H * s_spp / tc / 1e6, 4), "unit": "Msamples/s", "cores": nthr, "kind": "port",
                 "sample": f"same scene/camera/{wl.W}x{wl.H}/depth {wl.depth}/{wl.jl}, {s_spp} spp ({tc:.1f} s), oracle/ C port with OpenMP; "
@@ -430,6 +443,55 @@ def cpu_legs(wl, seconds):
     legs = [leg(16)] if threads >= 16 else []
     legs.append(leg(threads))
     return legs, (legs[0] if threads >= 16 else None)
+
+
+def in_library_leg(c, wl, n_devices, numerics, steps=2):
+    """The in-library device list (rtw_params.n_devices / device_ids: `render(...; devices=...)` of the Julia shim): K host-buffer calls per
+    gather path, timed like `value_end_to_end`.  `n_devices` beyond the visible devices: ordinals repeat -- the shards then share a device
+    (same code path up to the copy: rtw_stats_t.gather_path says SAME_DEVICE) and the RCCL variant runs on the distinct ordinals only."""
+    R, torch = c.R, c.torch
+    have = torch.cuda.device_count()
+    ids = [k % have for k in range(n_devices)]
+    emulation = n_devices > have
+    out = {"n_devices": n_devices, "visible_devices": have, "emulation": emulation,
+           "test_aids_env": {k: os.environ[k] for k in ("RTW_ENABLE_TEST_AIDS", "RTW_DEBUG_REMOTE_SHARDS", "RTW_DEBUG_NO_PEER") if k in os.environ} or None,
+           "workload": f"{wl.W}x{wl.H}, {wl.spp} spp, depth {wl.depth}, {wl.jl}, numerics {numerics}"}
+    names = {1: "peer", 2: "host_staged", 4: "rccl_reduce", 8: "same_device"}
+    sha_of = lambda im: hashlib.sha256(c.np.ascontiguousarray(im.transpose(1, 0, 2)).tobytes()).hexdigest()     # the column-major Matrix{RGB{T}} bytes, like Workload.frame_sha256
+    # (librccl prints a version banner on stdout when its first communicator is made: this process's stdout carries ONE JSON line, so
+    #  file descriptor 1 points at stderr while the leg runs)
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    for key, kw in (("peer", dict(devices=ids)), ("rccl_reduce", dict(devices=sorted(set(ids)), rccl_reduce=True))):
+        try:
+            def call():
+                img = R.render(wl.scene, wl.cam, wl.W, wl.spp, depth=wl.depth, seed=1, n_chunks=c.args.chunks, numerics=numerics, **kw)
+                return img, R.last_stats()
+            t = time.perf_counter()
+            img, st = call()                                     # first call: contexts, scene uploads, peer access / communicators
+            first_ms = (time.perf_counter() - t) * 1e3
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                img, st = call()
+            dt = (time.perf_counter() - t0) / steps
+            out[key] = {"devices": kw["devices"], "value": round(wl.W * wl.H * wl.spp / dt / 1e6, 2), "unit": "Msamples/s", "ms": round(dt * 1e3, 3),
+                        "first_call_ms": round(first_ms, 3), "steps": steps, "kernel_ms_max": round(st["kernel_ms"], 3),
+                        "per_device_kernel_ms": [{"device": d, "kernel_ms": round(ms, 3)} for d, ms in st["per_device"]],
+                        "gather_path": st["gather_path"], "gather_path_names": [v for k, v in names.items() if st["gather_path"] & k],
+                        "segments": st["segments"], "frame_sha256": sha_of(img)}
+        except Exception as e:                                   # (e.g. librccl missing: the leg says so instead of killing the line)
+            out[key] = {"error": str(e)[:300]}
+    out["sha_of"] = sha_of
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)                           # (the banner sits in C stdio's buffer: out with it while fd 1 is still stderr)
+    except Exception:
+        pass
+    os.dup2(saved_fd, 1)
+    os.close(saved_fd)
+    return out
 
 
 def cfg_name(dtype, W, spp, depth, world):
@@ -447,6 +509,19 @@ def main():
 
     wl = Workload(c, args.dtype, args.width, args.spp, args.depth)
     W, H, spp, depth = wl.W, wl.H, wl.spp, wl.depth
+    if args.in_library_devices > 0:                             # this leg only (tools/gpu_multi.sh; one process, the library drives the devices)
+        if world != 1:
+            raise SystemExit("--in-library-devices is a one-process mode (the library itself uses the devices)")
+        leg = in_library_leg(c, wl, args.in_library_devices, args.numerics, steps=max(1, args.steps))
+        one = c.R.render(wl.scene, wl.cam, W, spp, depth=depth, seed=1, n_chunks=args.chunks, numerics=args.numerics, device=0)
+        leg["one_device_frame_sha256"] = leg.pop("sha_of")(one)
+        leg["one_device_kernel_ms"] = round(c.R.last_stats()["kernel_ms"], 3)
+        for k in ("peer", "rccl_reduce"):
+            if "frame_sha256" in leg.get(k, {}):
+                leg[k]["frame_sha256_equal"] = leg[k]["frame_sha256"] == leg["one_device_frame_sha256"]
+        print(json.dumps({"in_library_devices": leg}), flush=True)
+        wl.close()
+        return
     stats, coll = [], []
     dt = wl.timed(args.steps, args.warmup, cull=args.group_cull, depth=depth, record=stats, valu=args.scan_valu, coll_ms=coll)
     sha = wl.frame_sha256() if rank == 0 else None
@@ -480,17 +555,19 @@ def main():
                  "value": round(samples_per_step * args.steps / dta / 1e6, 2), "unit": "Msamples/s",
                  "ms_per_step": round(dta / args.steps * 1e3, 3), "frame_sha256_equal": (wl.frame_sha256() == sha) if rank == 0 else None}
     if extras and not args.group_cull and not args.scan_valu:
-        dtv = wl.timed(1, 0, cull=False, depth=depth, valu=True)
-        scan_valu = {"mode": "RTW_FLAG_SCAN_VALU (contract discriminant for every sphere on the vector ALUs; same image bit for bit)",
-                     "value": round(samples_per_step / dtv / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtv * 1e3, 3),
+        nv = max(1, min(args.steps, 2))
+        dtv = wl.timed(nv, 1, cull=False, depth=depth, valu=True) / nv
+        scan_valu = {"mode": "RTW_FLAG_SCAN_VALU (the discriminant of the numerics mode for every sphere on the vector ALUs: no filter, no margin constants; same image bit for bit)",
+                     "value": round(samples_per_step / dtv / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtv * 1e3, 3), "steps": nv, "warmup": 1,
                      "frame_sha256_equal": (wl.frame_sha256() == sha) if rank == 0 else None}
     ray_pool = None
     if extras and not (args.group_cull or args.scan_valu or args.ray_pool) and args.dtype == "f32":
         stp_ = []
-        dtp_ = wl.timed(1, 0, cull=False, depth=depth, pool=True, record=stp_)
+        np_ = max(1, min(args.steps, 2))
+        dtp_ = wl.timed(np_, 1, cull=False, depth=depth, pool=True, record=stp_) / np_          # (one warm-up: the first launch loads the code object and sets the LDS attribute)
         ray_pool = {"mode": "RTW_FLAG_RAY_POOL (rays of a workgroup parked in LDS between the stages scan / shade / path end, every stage on full waves of one kind; "
                             "same image bit for bit; a measured LOSS on this chip, DESIGN.md section 6.4)",
-                    "value": round(samples_per_step / dtp_ / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtp_ * 1e3, 3),
+                    "value": round(samples_per_step / dtp_ / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtp_ * 1e3, 3), "steps": np_, "warmup": 1,
                     "block_threads": stp_[0]["block_threads"], "frame_sha256_equal": (wl.frame_sha256() == sha) if rank == 0 else None}
     if extras and depth != 16:
         st16 = []
@@ -498,6 +575,26 @@ def main():
         depth16 = {"value": round(samples_per_step / dt16 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt16 * 1e3, 3),
                    "segments_per_sample": round(st16[0]["segments"] * world / samples_per_step, 4) if world == 1 else None,
                    "note": "same workload at depth 16, the reference's only depth (src/ray_color.jl:14)"}
+    numerics_legs = in_lib = None
+    if extras and not (args.group_cull or args.scan_valu or args.ray_pool):
+        numerics_legs = {}
+        for mode in ("reference", "contract", "reference_fma"):
+            if mode == args.numerics:
+                continue
+            stn = []
+            nn = max(1, min(args.steps, 2))
+            dtn = wl.timed(nn, 1, cull=False, depth=depth, record=stn, numerics=mode) / nn
+            numerics_legs[mode] = {"value": round(samples_per_step / dtn / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtn * 1e3, 3), "steps": nn, "warmup": 1,
+                                   "segments_per_sample": round(stn[0]["segments"] * world / samples_per_step, 4) if world == 1 else None,
+                                   "frame_sha256": wl.frame_sha256() if rank == 0 else None,
+                                   "note": "a DIFFERENT image by design: another evaluation order of src/hit.jl:16-18 (DESIGN.md section 4)"}
+    if extras and world == 1:
+        have = torch.cuda.device_count()
+        in_lib = in_library_leg(c, wl, have if have > 1 else 2, args.numerics, steps=max(1, min(args.steps, 2)))
+        in_lib.pop("sha_of")
+        for k in ("peer", "rccl_reduce"):
+            if "frame_sha256" in in_lib.get(k, {}):
+                in_lib[k]["frame_sha256_equal"] = in_lib[k]["frame_sha256"] == sha
     if extras and world == 1:
         # SURVEY 8(d)'s metric -- the host-buffer entry point (what the Julia ccall binds): render + D2H of the image into the caller's
         # buffer, timed like `value` (the scene upload is cached by the library: the first call, reported separately, pays it)
@@ -517,7 +614,7 @@ def main():
         roofline = roofline_of(wl, k_s, sum(tests) / len(tests), all_segments / (samples_per_step * args.steps),
                                cull=args.group_cull, valu=args.scan_valu, world=world, shard_div=shard_div)
         if extras and world == 1 and not (args.group_cull or args.scan_valu or args.ray_pool) and not args.no_live_pmc:
-            pm = live_pmc(args.dtype, W, spp, depth)            # ~3 x 12 s; None on any failure (the static figures stay)
+            pm = live_pmc(args.dtype, W, spp, depth, args.numerics)            # ~3 x 12 s; None on any failure (the static figures stay)
             if pm:
                 roofline["traffic"], roofline["traffic_static"] = pm["traffic"], False
                 roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by THIS run (one launch each; FETCH_SIZE x 2 + WRITE_SIZE)"
@@ -548,7 +645,9 @@ def main():
                                 "plain linear scan over all spheres (reference algorithm): matrix-pipe filter + exact test of its candidates" +
                                 (", ray-pool kernel (RTW_FLAG_RAY_POOL)" if args.ray_pool else "")),
                        "parallelism": f"tile-sharded x{world}" + (f" + 1 RCCL {args.collective}" if world > 1 else ""),
-                       "rng": f"Xoroshiro128+ per (pixel, chunk), {stats[0]['n_chunks']} chunks/pixel; exact fixed-point pixel accumulation"},
+                       "rng": f"Xoroshiro128+ per (pixel, chunk), {stats[0]['n_chunks']} chunks/pixel; exact fixed-point pixel accumulation",
+                       "numerics": args.numerics + " (RTW_FLAG_NUMERICS_*: the evaluation order of the ray-sphere discriminant, src/hit.jl:16-18; "
+                                                   "reference = StaticArrays' un-fused dot, one rounding per written operation)"},
             "world_size_observed": dist.get_world_size() if world > 1 else 1, "backend": c.backend,
             "launched_by": "bench.py (self-spawned torch.distributed.run)" if os.environ.get("RTW_BENCH_SELF_SPAWNED") == "1" else
                            ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "python"),
@@ -557,6 +656,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_16t": cpu16,
             "cpu_baseline_all_threads": (legs[-1] if legs else None), "accelerated": accel,
             "scan_valu": scan_valu, "ray_pool": ray_pool, "end_to_end": end_to_end, "depth16": depth16,
+            "segments_per_sample": round(all_segments / (samples_per_step * args.steps), 4),
+            "numerics": args.numerics, "numerics_legs": numerics_legs, "in_library_devices": in_lib,
         }
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)

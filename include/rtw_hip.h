@@ -188,6 +188,11 @@ int rtw_render_device_f64(rtw_scene_handle scene, const rtw_camera_f64 *cam, con
 /* Counters/timings of the last render issued from this thread (waits for it to finish). */
 int rtw_stats(rtw_stats_t *out);
 
+/* The shards of the last render issued from this thread, one entry per shard in shard order (a device list of N: N entries; one
+ * device: one): the HIP ordinal it ran on and the HIP-event time of its trace kernel.  *count receives the number of shards; at most
+ * `capacity` entries are written.  (rtw_stats_t.kernel_ms is the maximum of these.) */
+int rtw_stats_devices(int32_t capacity, int32_t *count, int32_t *devices, double *kernel_ms);
+
 /* Unit-level device entry points used by the parity tests (tier T0): each evaluates the
  * device implementation of one reference function on `count` inputs, one lane per input.
  * All pointers are HOST pointers; layouts are documented in tests/test_gpu_units.py.

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("RTW_HIP_LIB") or os.path.join(_HERE, "lib", "librtw_h
 SYMBOLS = [
     "rtw_abi_version", "rtw_device_count", "rtw_last_error", "rtw_render_f32", "rtw_render_f64",
     "rtw_scene_upload_f32", "rtw_scene_upload_f64", "rtw_scene_free", "rtw_render_device_f32",
-    "rtw_render_device_f64", "rtw_stats", "rtw_unit_f32", "rtw_unit_f64", "rtw_shutdown",
+    "rtw_render_device_f64", "rtw_stats", "rtw_stats_devices", "rtw_unit_f32", "rtw_unit_f64", "rtw_shutdown",
 ]
 
 
@@ -77,6 +77,7 @@ def lib():
     L.rtw_render_f32.argtypes = [C.POINTER(SceneF32), C.POINTER(CameraF32), C.POINTER(Params), C.c_void_p]
     L.rtw_render_f64.argtypes = [C.POINTER(SceneF64), C.POINTER(CameraF64), C.POINTER(Params), C.c_void_p]
     L.rtw_stats.argtypes = [C.POINTER(Stats)]
+    L.rtw_stats_devices.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.rtw_unit_f32.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(SceneF32), C.POINTER(CameraF32)]
     L.rtw_unit_f64.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(SceneF64), C.POINTER(CameraF64)]
     _lib = L

@@ -90,6 +90,7 @@ void release_last() {
     g_last.resolved = false;
     g_last.generation = g_generation.load();
     memset(&g_last.agg, 0, sizeof g_last.agg);
+    g_last.per_device.clear();
 }
 LastRender::~LastRender() {
     if (generation == g_generation.load())
@@ -197,11 +198,29 @@ int rtw_stats(rtw_stats_t *out) {
     DeviceGuard guard;
     if (!g_last.resolved) {
         memset(&g_last.agg, 0, sizeof g_last.agg);
-        for (RenderRec *r : g_last.recs)
-            if (int rc = resolve_rec(r, &g_last.agg)) return rc;
+        g_last.per_device.clear();
+        for (RenderRec *r : g_last.recs) {
+            rtw_stats_t one;
+            memset(&one, 0, sizeof one);
+            if (int rc = resolve_rec(r, &one)) return rc;
+            g_last.per_device.emplace_back(r->device, one.kernel_ms);
+            rtw_stats_t &a = g_last.agg;
+            a.samples += one.samples; a.segments += one.segments; a.sphere_tests += one.sphere_tests;
+            a.kernel_ms = std::max(a.kernel_ms, one.kernel_ms); a.total_ms = std::max(a.total_ms, one.total_ms);
+            a.n_chunks = one.n_chunks; a.grid_blocks = std::max(a.grid_blocks, one.grid_blocks); a.block_threads = std::max(a.block_threads, one.block_threads);
+        }
         g_last.resolved = true;
     }
     *out = g_last.agg;
+    return 0;
+}
+
+int rtw_stats_devices(int32_t capacity, int32_t *count, int32_t *devices, double *kernel_ms) {
+    if (!count || capacity < 0 || (capacity > 0 && (!devices || !kernel_ms))) return fail(-1, "null argument");
+    rtw_stats_t st;
+    if (int rc = rtw_stats(&st)) return rc;                    // (resolves a pending device-resident render)
+    *count = (int32_t)g_last.per_device.size();
+    for (int32_t k = 0; k < capacity && k < *count; ++k) { devices[k] = g_last.per_device[(size_t)k].first; kernel_ms[k] = g_last.per_device[(size_t)k].second; }
     return 0;
 }
 

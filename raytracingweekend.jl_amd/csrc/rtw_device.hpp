@@ -690,7 +690,8 @@ struct MfmaCull {
     const uint4 *ops;
     const float *box;
     int blocks;
-    float cs[3], rs;      // bounding sphere of the small class (the slab margin grows with the distance to it)
+    float cs[3], rs;      // bounding sphere of the small class (the margin grows with the distance to it)
+    float glo[3], ghi[3]; // the box of the whole small class (the union of its blocks' boxes): a ray is clipped against it ONCE per scan
     int n_huge, huge[2];  // huge spheres (device order), tested in-lane like DevScene::huge
 };
 
@@ -921,19 +922,49 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     unsigned total = 0;                                   // wave-uniform
     const uint4 *pa = (CULLED ? mc->ops : w.mf_ops) + lane;
     const int n_blocks = CULLED ? mc->blocks : w.mf_blocks;
-    // group cull: per-ray constants of the slab test (see hit_world_cull for the margin)
-    [[maybe_unused]] float cinv[3] = {0, 0, 0}, cmargin = 0;
+    // Group cull: the per-ray side of the block vote.  A sphere of a block can only be hit if the RAY (t >= 0) meets the block's box grown
+    // by the margin m (hit_world_cull derives m).  Round 4 ran that slab test per (lane, block): 23 VALU instructions x 17 blocks, about
+    // what the skipped blocks saved.  Round 5: the ray is clipped ONCE per scan against the box of the whole small class grown by m
+    // (the union of the blocks' boxes: every grown block box lies inside it), which leaves a segment [tn, tf] of the ray; every point of
+    // the ray inside any grown block box lies on that segment, hence inside the segment's axis-aligned bounds [pmin, pmax].  Per block
+    // the vote is then the overlap of two boxes -- 6 subtractions and 3 maxima against the block's bounds held in SGPRs:
+    //     touch  <=>  lo_b - m <= pmax + delta  and  hi_b + m >= pmin - delta        (per axis)
+    // with delta the rounding of tn, tf and the two end points (a few ulps of |o| + tf |d|: below 1e-6 of the distances m is
+    // proportional to with a factor >= 2^-8), covered by using m for it: pming = pmin - 2m, pmaxg = pmax + 2m.  For the flat layer of
+    // small spheres of the reference's scenes the segment is short (the ray crosses the layer), so the bounds are as tight as the slab
+    // test; a ray running along the layer gets loose bounds -- conservative, never wrong.  A ray that misses the small class's box
+    // touches no block of it; a ray that does not use the filter (not ok) touches every block; the BIG class's blocks carry infinite
+    // bounds (never skipped); lanes without a ray are masked out of the vote.
+    [[maybe_unused]] float pming[3] = {0, 0, 0}, pmaxg[3] = {0, 0, 0};
+    [[maybe_unused]] unsigned long long ray_mask = 0;
     typedef const float __attribute__((address_space(4))) *cfptr;
     [[maybe_unused]] cfptr gbox = nullptr;
     if constexpr (CULLED) {
         gbox = (cfptr)(uintptr_t)mc->box;
+        ray_mask = __ballot(has_ray);
         const float ex = ox - mc->cs[0], ey = oy - mc->cs[1], ez = oz - mc->cs[2];
         const float eps_p = (s2 > 1.0f ? s2 - 1.0f : 0.0f) + 2.4e-7f * s2;
-        const float margin = (0.00390625f * (s2 > 1.0f ? s2 : 1.0f) + 2.0f * __builtin_sqrtf(eps_p)) *
-                             ((__builtin_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) + mc->rs) + 1.0f);
-        auto safe_inv = [](float x) { const float e = 1e-9f; const float y = (x < e && x > -e) ? (x < 0.0f ? -e : e) : x; return 1.0f / y; };
-        cinv[0] = safe_inv(dx); cinv[1] = safe_inv(dy); cinv[2] = safe_inv(dz);
-        cmargin = margin;                                 // (o +- margin is formed per block: 6 more VALU, 5 fewer live registers)
+        // (hardware approximations v_sqrt_f32 / v_rcp_f32, 1 ulp: m is inflated by 2^-10 for them, and the reciprocals only place the end
+        //  points of the clip, whose rounding the 2 m of slack covers a thousandfold -- the IEEE forms cost 65 instructions per scan)
+        const float m = 1.001f * (0.00390625f * (s2 > 1.0f ? s2 : 1.0f) + 2.0f * __builtin_amdgcn_sqrtf(eps_p)) *
+                        ((__builtin_amdgcn_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) + mc->rs) + 1.0f);
+        auto safe_inv = [](float x) { const float e = 1e-9f; const float y = (x < e && x > -e) ? (x < 0.0f ? -e : e) : x; return __builtin_amdgcn_rcpf(y); };
+        const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+        const float x0 = ((mc->glo[0] - m) - ox) * ix, x1 = ((mc->ghi[0] + m) - ox) * ix;
+        const float y0 = ((mc->glo[1] - m) - oy) * iy, y1 = ((mc->ghi[1] + m) - oy) * iy;
+        const float z0 = ((mc->glo[2] - m) - oz) * iz, z1 = ((mc->ghi[2] + m) - oz) * iz;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1)), 0.0f);
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+        const float m2 = m + m;
+        const float ax = __builtin_fmaf(tn, dx, ox), ay = __builtin_fmaf(tn, dy, oy), az = __builtin_fmaf(tn, dz, oz);
+        const float bx = __builtin_fmaf(tf, dx, ox), by = __builtin_fmaf(tf, dy, oy), bz = __builtin_fmaf(tf, dz, oz);
+        const bool hits_class = !(tf < tn);                  // (a NaN anywhere: treated as "meets the class"; its bounds are then made infinite below)
+        const bool finite = (ax - ax) + (ay - ay) + (az - az) + (bx - bx) + (by - by) + (bz - bz) + (m - m) == 0.0f;
+        const float big = 3.0e38f, inf = __builtin_huge_valf();
+        pming[0] = __builtin_fminf(ax, bx) - m2; pming[1] = __builtin_fminf(ay, by) - m2; pming[2] = __builtin_fminf(az, bz) - m2;
+        pmaxg[0] = __builtin_fmaxf(ax, bx) + m2; pmaxg[1] = __builtin_fmaxf(ay, by) + m2; pmaxg[2] = __builtin_fmaxf(az, bz) + m2;
+        if (!hits_class) { pming[0] = pming[1] = pming[2] = big; pmaxg[0] = pmaxg[1] = pmaxg[2] = -big; }      // no block of the small class (the BIG class's bounds are +-inf: still touched)
+        if (!ok || !finite) { pming[0] = pming[1] = pming[2] = -inf; pmaxg[0] = pmaxg[1] = pmaxg[2] = inf; }    // every block
     }
     uint4 A1 = pa[0], A2 = pa[64];
     // Wave priority: low inside the block loop, raised for everything else (pass 2 and the divergent phases of the lane loop are
@@ -945,25 +976,23 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     constexpr bool use_prio = RTW_SCAN_PRIO != 0;
     if (use_prio) __builtin_amdgcn_s_setprio(sizeof(T) == 4 ? 0 : 1);
     for (int blk = 0; blk < n_blocks; ++blk) {
+        [[maybe_unused]] bool do_half0 = true, do_half1 = true;          // (wave-uniform) group cull: which ray halves of the wave can touch this block
         if constexpr (CULLED) {
             const float lx = gbox[8 * blk], ly = gbox[8 * blk + 1], lz = gbox[8 * blk + 2];
             const float hx = gbox[8 * blk + 4], hy = gbox[8 * blk + 5], hz = gbox[8 * blk + 6];
-            float mg = cmargin;
-            __asm__ volatile("" : "+v"(mg));              // (keeps o +- m from being hoisted into six loop-long registers)
-            const float x0 = (lx - (ox + mg)) * cinv[0], x1 = (hx - (ox - mg)) * cinv[0];      // lo' - o = lo - (o + m), hi' - o = hi - (o - m)
-            const float y0 = (ly - (oy + mg)) * cinv[1], y1 = (hy - (oy - mg)) * cinv[1];
-            const float z0 = (lz - (oz + mg)) * cinv[2], z1 = (hz - (oz - mg)) * cinv[2];
-            const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-            const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-            const float sgn = tf - __builtin_fmaxf(tn, 0.0f);
-            // a ray that does not use the filter (not ok) touches everything; a lane without a ray nothing
-            const bool touch = has_ray && (!ok || !(sgn < 0.0f));
+            // (the block's bounds are stored grown by nothing; m is on the ray's side: pming / pmaxg)
+            const float sep = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lx - pmaxg[0], ly - pmaxg[1]), lz - pmaxg[2]),
+                                              __builtin_fmaxf(__builtin_fmaxf(pming[0] - hx, pming[1] - hy), pming[2] - hz));
+            const unsigned long long touch = __ballot(!(sep > 0.0f)) & ray_mask;
             clk.count(7, 1u);
-            if (!__any(touch)) {
+            if (!touch) {
                 clk.count(6, 1u);
                 A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];      // (keeps the operand pipeline going)
                 continue;
             }
+            // lanes l and l + 32 hold the same 32 rays of a half wave: the two MFMA pairs of a block are the two RAY halves -- each is skipped by itself
+            do_half0 = (unsigned)touch != 0u;
+            do_half1 = (unsigned)(touch >> 32) != 0u;
         }
         unsigned mask = 0;
         bool any_cand = false;                               // (wave-uniform)
@@ -1043,21 +1072,23 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         };
         constexpr unsigned HB = 16u / RTW_SCAN_GROUP;       // mask bits per half block
         {
-            rtw_f16v Wv = filter_pair(A1, A2, B1[0], B2[0]);
+            rtw_f16v Wv = zero;
+            if (!CULLED || do_half0) Wv = filter_pair(A1, A2, B1[0], B2[0]);
 #ifdef RTW_DUP_EVAL      // time probe: the sign collection twice
             { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
 #endif
 #if RTW_SCAN_CMP
-            if (!(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 0u, blk); }
+            if ((!CULLED || do_half0) && !(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 0u, blk); }
 #else
-            if (RTW_SCAN_SKIP && none(Wv)) mask = (1u << HB) - 1u;          // all negative
+            if ((CULLED && !do_half0) || (RTW_SCAN_SKIP && none(Wv))) mask = (1u << HB) - 1u;          // all negative
             else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }      // (the asm keeps it a real branch: no if-conversion)
 #endif
         }
         {
             // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
             // padding at the end), so only one set of A registers is live during the evaluation
-            rtw_f16v Wv = filter_pair(A1, A2, B1[1], B2[1]);
+            rtw_f16v Wv = zero;
+            if (!CULLED || do_half1) Wv = filter_pair(A1, A2, B1[1], B2[1]);
             __builtin_amdgcn_sched_barrier(0);
             A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];
             __builtin_amdgcn_sched_barrier(0);
@@ -1065,9 +1096,9 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
 #endif
 #if RTW_SCAN_CMP
-            if (!(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 16u, blk); }
+            if ((!CULLED || do_half1) && !(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 16u, blk); }
 #else
-            if (RTW_SCAN_SKIP && none(Wv)) mask = (mask << HB) | ((1u << HB) - 1u);
+            if ((CULLED && !do_half1) || (RTW_SCAN_SKIP && none(Wv))) mask = (mask << HB) | ((1u << HB) - 1u);
             else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }
 #endif
         }
@@ -1187,12 +1218,14 @@ template <typename T> struct CullScene {
     T kappa;
     const uint4 *mf_ops;                   // group cull on the matrix pipe (hit_world_mfma with MfmaCull): operands in this
     const float *mf_box;                   //   device order, one binary32 box per block of 32
+    float mf_glo[3], mf_ghi[3];            //   ... and the box of the whole small class (the union of those boxes; an empty class: lo > hi)
     int mf_blocks;
     int n_huge, huge[2];                   // huge spheres in this order (see DevScene::huge)
     int numerics;                          // NUM_* (see DevScene::numerics)
 };
 template <typename T> __host__ __device__ inline MfmaCull mfma_cull_of(const CullScene<T> &c) {
-    return MfmaCull{c.mf_ops, c.mf_box, c.mf_blocks, {(float)c.cs[0], (float)c.cs[1], (float)c.cs[2]}, (float)c.rs * 1.000001f + 1e-30f, c.n_huge, {c.huge[0], c.huge[1]}};
+    return MfmaCull{c.mf_ops, c.mf_box, c.mf_blocks, {(float)c.cs[0], (float)c.cs[1], (float)c.cs[2]}, (float)c.rs * 1.000001f + 1e-30f,
+                    {c.mf_glo[0], c.mf_glo[1], c.mf_glo[2]}, {c.mf_ghi[0], c.mf_ghi[1], c.mf_ghi[2]}, c.n_huge, {c.huge[0], c.huge[1]}};
 }
 template <typename T> __host__ __device__ inline int cull_exact_count(const CullScene<T> &c) { return c.n_groups_pad * RTW_CULL_GS + ((c.n_big + 31) / 32) * 32; }   // (allocated in whole blocks of 32: dead slots behind the BIG class)
 

@@ -48,6 +48,7 @@ struct rtw_scene_dev {
     int n_huge, huge[2];   // spheres that pass the filter for nearly every ray (a ground sphere): tested exactly by every lane, their filter rows disabled
     // group-cull mode on the matrix pipe: the same operands in the cluster-major order + one box per block of 32
     void *c_mf_ops, *c_mf_box;
+    float c_glo[3], c_ghi[3];   // the box of the whole small class (union of the block boxes): the ray is clipped against it once per scan
     int c_mf_blocks;
     int c_huge[2];         // the huge spheres' indices in the cluster-major order (n_huge of them)
     // opt-in group-cull mode (RTW_FLAG_GROUP_CULL): cluster-major copies
@@ -152,6 +153,7 @@ struct LastRender {
     std::vector<RenderRec *> recs;          // pending (device-resident call) or already summed into `agg`
     std::vector<CtxPtr> ctxs;               // the contexts that own `recs` (kept alive; parallel to recs)
     rtw_stats_t agg;
+    std::vector<std::pair<int, double>> per_device;   // (device ordinal, kernel ms) of every shard of the last render, in shard order (rtw_stats_devices)
     ~LastRender();                          // a thread that exits hands its records back
 };
 extern thread_local LastRender g_last;

@@ -149,6 +149,7 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
         if (!rc) rc = copy_out(hc, hc->d_img, out, elems * sizeof(T));
         if (rc) (void)hipStreamSynchronize(hc->stream);           // nothing of this call may still be in flight when the lease ends
         if (!rc) rc = resolve_rec(rec, &g_last.agg);
+        if (!rc) g_last.per_device.emplace_back(hc->device, g_last.agg.kernel_ms);
         if (rec) release_rec(rctx, rec, rc == 0);
         g_last.resolved = rc == 0;
         return rc;
@@ -278,6 +279,7 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
         memset(&st, 0, sizeof st);
         if (!rc) rc = resolve_rec(recs[r], &st);
         release_rec(rctx[r], recs[r], rc == 0);
+        if (!rc) g_last.per_device.emplace_back(recs[r]->device, st.kernel_ms);
         a.samples += st.samples; a.segments += st.segments; a.sphere_tests += st.sphere_tests;
         a.kernel_ms = std::max(a.kernel_ms, st.kernel_ms); a.total_ms = std::max(a.total_ms, st.total_ms);
         a.n_chunks = st.n_chunks; a.grid_blocks = std::max(a.grid_blocks, st.grid_blocks); a.block_threads = std::max(a.block_threads, st.block_threads);

@@ -143,7 +143,7 @@ int build_cull(const SceneT *s, rtw_scene_dev *h) {
             }
             float *q = &bx[(size_t)b * 8];
             for (int a = 0; a < 3; ++a) {
-                if (all) { q[a] = -3.0e38f; q[4 + a] = 3.0e38f; }
+                if (all) { q[a] = -INFINITY; q[4 + a] = INFINITY; }                          // never skipped (the vote of hit_world_mfma)
                 else if (!any) { q[a] = 1e15f; q[4 + a] = 1e15f; }                            // nothing alive: a point far away
                 else {
                     float l = (float)lo[a], u2 = (float)hi[a];
@@ -152,6 +152,13 @@ int build_cull(const SceneT *s, rtw_scene_dev *h) {
                     q[a] = l; q[4 + a] = u2;
                 }
             }
+        }
+        // the box of the whole small class: the union of the live, finite block boxes (none: lo > hi, every ray misses it)
+        for (int a = 0; a < 3; ++a) { h->c_glo[a] = INFINITY; h->c_ghi[a] = -INFINITY; }
+        for (int b = 0; b < nb; ++b) {
+            const float *q = &bx[(size_t)b * 8];
+            if (!std::isfinite(q[0]) || q[0] >= 1e15f) continue;                                   // BIG class / nothing alive
+            for (int a = 0; a < 3; ++a) { h->c_glo[a] = std::min(h->c_glo[a], q[a]); h->c_ghi[a] = std::max(h->c_ghi[a], q[4 + a]); }
         }
         HIP_TRY(hipMalloc(&h->c_mf_box, bx.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->c_mf_box, bx.data(), bx.size() * sizeof(float), hipMemcpyHostToDevice));

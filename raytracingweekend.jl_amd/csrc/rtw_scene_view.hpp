@@ -15,6 +15,7 @@ rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
     C.cs[0] = (T)h->c_cs[0]; C.cs[1] = (T)h->c_cs[1]; C.cs[2] = (T)h->c_cs[2]; C.rs = (T)h->c_rs;
     C.kappa = sizeof(T) == 4 ? (T)0.00390625 : (T)2.384185791015625e-07;     // 2^-8 / 2^-22
     C.mf_ops = (const uint4 *)h->c_mf_ops; C.mf_box = (const float *)h->c_mf_box; C.mf_blocks = h->c_mf_blocks;
+    for (int k = 0; k < 3; ++k) { C.mf_glo[k] = h->c_glo[k]; C.mf_ghi[k] = h->c_ghi[k]; }
     C.n_huge = h->c_mf_ops ? h->n_huge : 0; C.huge[0] = h->c_huge[0]; C.huge[1] = h->c_huge[1];
     C.numerics = rtw::NUM_REFERENCE;
     return C;

@@ -58,8 +58,18 @@ def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chun
     st = _capi.Stats()
     _capi.check(L.rtw_stats(C.byref(st)))
     _tls.stats = {k: getattr(st, k) for k, _ in st._fields_}
+    _tls.stats["per_device"] = _stats_devices(L)
     del keep
     return _as_image(out, height, int(image_width))
+
+
+def _stats_devices(L, cap=64):
+    """[(HIP ordinal, kernel ms)] of the shards of the calling thread's last render (rtw_stats_devices)"""
+    n = C.c_int32(0)
+    dev = (C.c_int32 * cap)()
+    ms = (C.c_double * cap)()
+    _capi.check(L.rtw_stats_devices(cap, C.byref(n), dev, ms))
+    return [(int(dev[k]), float(ms[k])) for k in range(min(cap, n.value))]
 
 
 def last_stats():

@@ -187,16 +187,17 @@ import numpy as np
 import torch
 torch.cuda.init()
 import rtw_amd as R
-T = np.float32
+spec = json.loads(sys.argv[1])
+T = np.float64 if spec.pop("__dtype__", "f32") == "f64" else np.float32
 R.reseed()
 scene = R.scene_random_spheres(elem_type=T)
 cam = R.t_cam1(elem_type=T)
-spec = json.loads(sys.argv[1])
 out = {}
 for name, kw in spec.items():
     img = R.render(scene, cam, 200, 12, depth=16, seed=5, **kw)
     st = R.last_stats()
-    out[name] = {"sha": hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest(), "gather_path": st["gather_path"], "segments": st["segments"]}
+    out[name] = {"sha": hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest(), "gather_path": st["gather_path"], "segments": st["segments"],
+                 "per_device": st["per_device"]}
 print(json.dumps(out))
 """
 
@@ -211,18 +212,28 @@ def _probe(spec, env_extra=None):
     return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
 
 
-def test_gather_branches_on_one_device():
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_gather_branches_on_one_device(dtype):
     """The branches of the in-library multi-device gather that a one-GPU box cannot reach by itself, forced by the test aids of
     the library (RTW_ENABLE_TEST_AIDS=1): RTW_DEBUG_REMOTE_SHARDS=1 makes every shard but the first render into its own buffer and COPY it into the gather
     buffer (hipMemcpyPeerAsync, the cross-device branch); with RTW_DEBUG_NO_PEER=1 the copy takes the host-staged fallback (pinned
-    staging, D2H + H2D) that a platform without peer access gets.  Same frame as one device, and rtw_stats_t.gather_path says which ran."""
-    one = _probe({"one": {}})["one"]
-    same = _probe({"x": {"devices": [0, 0, 0]}})["x"]
+    staging, D2H + H2D) that a platform without peer access gets; and the RCCL reduce (one rank: a communicator holds a GPU once).  Same
+    frame as one device in both precisions, rtw_stats_t.gather_path says which ran, rtw_stats_devices lists every shard."""
+    aids = {"RTW_ENABLE_TEST_AIDS": "1"}
+    one = _probe({"__dtype__": dtype, "one": {}})["one"]
+    assert one["per_device"] == [[0, one["per_device"][0][1]]] and one["per_device"][0][1] > 0
+    same = _probe({"__dtype__": dtype, "x": {"devices": [0, 0, 0]}})["x"]
     assert same["sha"] == one["sha"] and same["gather_path"] == 8 and same["segments"] == one["segments"]          # RTW_GATHER_SAME_DEVICE
-    peer = _probe({"x": {"devices": [0, 0, 0]}}, {"RTW_ENABLE_TEST_AIDS": "1", "RTW_DEBUG_REMOTE_SHARDS": "1"})["x"]
+    assert [d for d, _ in same["per_device"]] == [0, 0, 0] and all(ms > 0 for _, ms in same["per_device"])
+    peer = _probe({"__dtype__": dtype, "x": {"devices": [0, 0, 0]}}, dict(aids, RTW_DEBUG_REMOTE_SHARDS="1"))["x"]
     assert peer["sha"] == one["sha"] and peer["gather_path"] == 1                                                # RTW_GATHER_PEER
-    staged = _probe({"x": {"devices": [0, 0, 0, 0, 0]}}, {"RTW_ENABLE_TEST_AIDS": "1", "RTW_DEBUG_REMOTE_SHARDS": "1", "RTW_DEBUG_NO_PEER": "1"})["x"]
+    staged = _probe({"__dtype__": dtype, "x": {"devices": [0, 0, 0, 0, 0]}}, dict(aids, RTW_DEBUG_REMOTE_SHARDS="1", RTW_DEBUG_NO_PEER="1"))["x"]
     assert staged["sha"] == one["sha"] and staged["gather_path"] == 2                                            # RTW_GATHER_HOST_STAGED
+    rccl = _probe({"__dtype__": dtype, "x": {"devices": [0], "rccl_reduce": True}})["x"]
+    assert rccl["sha"] == one["sha"] and rccl["gather_path"] == 4                                                # RTW_GATHER_RCCL
+    # without the master switch the aids are dead: the same-device path again
+    dead = _probe({"__dtype__": dtype, "x": {"devices": [0, 0, 0]}}, {"RTW_DEBUG_REMOTE_SHARDS": "1"})["x"]
+    assert dead["gather_path"] == 8 and dead["sha"] == one["sha"]
 
 
 def test_in_library_rccl_reduce_one_rank():
@@ -341,3 +352,11 @@ def test_bench_line_contract_and_live_counters():
     assert d["collective_ms"] == 0.0 and d["render_ms_max"] == d["render_ms_min"] > 0
     # (the f64 legs belong to the headline workload only: --spp 16 is not it)
     assert d["f64_4k"] is None and d["f64_1080p_d16"] is None
+    # round 5: the numerics mode and its counter in the line, the other modes as legs with their own (different) frames, the in-library device list
+    assert d["numerics"] == "reference" and d["config"]["numerics"].startswith("reference") and 3.0 < d["segments_per_sample"] < 5.0
+    nl = d["numerics_legs"]
+    assert set(nl) == {"contract", "reference_fma"} and nl["contract"]["frame_sha256"] != d["frame_sha256"]
+    assert nl["contract"]["segments_per_sample"] < nl["reference_fma"]["segments_per_sample"] < d["segments_per_sample"]
+    il = d["in_library_devices"]
+    assert il["n_devices"] >= 2 and il["peer"]["frame_sha256_equal"] is True and il["rccl_reduce"]["frame_sha256_equal"] is True
+    assert len(il["peer"]["per_device_kernel_ms"]) == il["n_devices"] and il["rccl_reduce"]["gather_path_names"] == ["rccl_reduce"]

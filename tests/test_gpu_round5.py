@@ -101,3 +101,26 @@ def test_stray_environment_switches_change_nothing():
     assert valu["sha"] == base["sha"] and valu["grid"] != base["grid"]                  # the all-VALU kernel runs 7 waves per SIMD, not 5
     pool = _aid_probe({"RTW_ENABLE_TEST_AIDS": "1", "RTW_POOL": "1"})
     assert pool["sha"] == base["sha"] and pool["block"] == 1024
+
+
+# ---- the in-library device list as bench.py times it --------------------------------------------------------------------------
+def test_bench_in_library_devices_leg():
+    """`python bench.py --in-library-devices N` (tools/gpu_multi.sh calls nothing else for this path): host-buffer entry point with a device
+    list, peer gather and the in-library RCCL reduce, per-device kernel times, gather path, frame equal to the one-device frame.  On a
+    one-GPU box the ordinals repeat and the leg says so (`emulation`)."""
+    from test_gpu_round3 import _bench
+    import torch
+    have = torch.cuda.device_count()
+    n = max(2, have)
+    p, d = _bench(["--in-library-devices", str(n), "--steps", "1", "--spp", "8", "--width", "640"], timeout=600)
+    assert p.returncode == 0 and d is not None, p.stderr[-3000:]
+    il = d["in_library_devices"]
+    assert il["n_devices"] == n and il["emulation"] == (n > have)
+    for k in ("peer", "rccl_reduce"):
+        assert il[k]["frame_sha256_equal"] is True and il[k]["ms"] > 0 and il[k]["kernel_ms_max"] > 0, (k, il[k])
+    assert len(il["peer"]["per_device_kernel_ms"]) == n
+    assert il["rccl_reduce"]["gather_path_names"] == ["rccl_reduce"]
+    if have > 1:
+        assert il["peer"]["gather_path_names"] in (["peer"], ["host_staged"], ["peer", "same_device"])
+    else:
+        assert il["peer"]["gather_path_names"] == ["same_device"]

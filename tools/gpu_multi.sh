@@ -1,12 +1,12 @@
 #!/bin/bash
 # What to run on the first box with more than one MI355X: the multi-GPU tests (they skip on one GPU), then the headline bench at
 # N = 1, 2, 4, 8 (as many as are visible) with both collectives, one JSON line per run, and the in-library device list (peer copies
-# and RTW_FLAG_RCCL_REDUCE) timed through the host-buffer entry point.  usage: tools/gpu_multi.sh [outdir=gpurun_out/multi]
+# and RTW_FLAG_RCCL_REDUCE) through the host-buffer entry point -- all of it by bench.py (`--gpus N`, `--in-library-devices N`).  usage: tools/gpu_multi.sh [outdir=gpurun_out/multi]
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=${1:-$R/gpurun_out/multi}; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 NG=$(python -c "import torch; print(torch.cuda.device_count())")
 echo "visible devices: $NG"
-timeout 1200 python -m pytest tests/test_gpu_round4.py -q -k "multi_gpu or gather or rccl" -rs 2>&1 | tail -8
+timeout 1200 python -m pytest tests/test_gpu_round4.py tests/test_gpu_round5.py -q -k "multi_gpu or gather or rccl or in_library" -rs 2>&1 | tail -8
 for N in 1 2 4 8; do
   [ $N -le $NG ] || continue
   for C in reduce gather; do
@@ -23,18 +23,19 @@ except Exception as e:
 PY
   done
 done
-python3 - <<PY
-import time, numpy as np, torch
-torch.cuda.init()
-import rtw_amd as R
-T = np.float32; R.reseed(); scene = R.scene_random_spheres(elem_type=T); cam = R.t_cam1(elem_type=T)
-ng = torch.cuda.device_count()
-for n in (1, 2, 4, 8):
-    if n > ng: continue
-    for rccl in (False, True):
-        kw = dict(devices=list(range(n)), rccl_reduce=rccl) if (n > 1 or rccl) else {}
-        R.render(scene, cam, 1920, 1000, depth=50, **kw)                  # first call: uploads, communicator
-        t = time.perf_counter(); img = R.render(scene, cam, 1920, 1000, depth=50, **kw); dt = time.perf_counter() - t
-        st = R.last_stats()
-        print("in-library N=%d %s: %.2f ms  %.1f Msamples/s  kernel max %.2f ms  gather_path %d" % (n, "rccl" if rccl else "peer", dt * 1e3, 1920 * 1080 * 1000 / dt / 1e6, st["kernel_ms"], st["gather_path"]))
+# the in-library device list (one process; what a Julia caller gets with devices=...): bench.py times it -- peer copies and the RCCL reduce
+for N in 1 2 4 8; do
+  [ $N -le $NG ] || continue
+  timeout 900 python bench.py --in-library-devices $N --steps 3 > $O/bench_inlib_n${N}.json 2> $O/bench_inlib_n${N}.err
+  python3 - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_inlib_n${N}.json"))["in_library_devices"]
+    for k in ("peer", "rccl_reduce"):
+        v = d[k]
+        print("in-library N=$N %-11s: %s" % (k, v.get("error") or "%.2f ms  %.1f Msamples/s  kernel max %.2f ms  per device %s  gather_path %s  frame equal %s" % (
+            v["ms"], v["value"], v["kernel_ms_max"], [x["kernel_ms"] for x in v["per_device_kernel_ms"]], v["gather_path_names"], v.get("frame_sha256_equal"))))
+except Exception as e:
+    print("in-library N=$N: FAILED", e); print(open("$O/bench_inlib_n${N}.err").read()[-1500:])
 PY
+done

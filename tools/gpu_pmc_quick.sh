@@ -19,7 +19,9 @@ for tag in "ABC":
     for f in glob.glob("$O/%s/*kernel_trace.csv" % tag):
         for row in csv.DictReader(open(f)):
             if "trace" in row["Kernel_Name"]: dur[tag] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
-segs = 1920 * 1080 * $SPP * 3.9438; ws = segs / 64
+import re
+sps = float(re.search(r"segs/sample ([0-9.]+)", open("$O/A.log").read()).group(1))      # counted by the kernel (depends on the numerics mode)
+segs = 1920 * 1080 * $SPP * sps; ws = segs / 64
 cyc = tot["GRBM_GUI_ACTIVE"] / 8; simd = 1024 * cyc
 print("kernel ms per pass", dur)
 print("per wave-segment: VALU %.0f  SALU %.0f  MFMA %.1f  LDS %.1f  VMEM %.1f  SMEM %.2f" % (tot["SQ_INSTS_VALU"] / ws, tot["SQ_INSTS_SALU"] / ws, tot["SQ_INSTS_MFMA"] / ws, tot["SQ_INSTS_LDS"] / ws, tot["SQ_INSTS_VMEM"] / ws, tot["SQ_INSTS_SMEM"] / ws))
