@@ -181,6 +181,22 @@ def test_check_julia_kat_detects_a_wrong_assumption(tmp_path):
     assert "FAIL" in line and r.stdout.count("FAIL") == 2        # that item and the summary line
 
 
+@pytest.mark.parametrize("mode", ["reference", "contract", "reference_fma", "reference_fma2"])
+def test_check_julia_kat_names_the_numerics_mode(tmp_path, mode):
+    """The dump of a Julia whose hit(::Sphere) evaluates src/hit.jl:16-18 in any of the oracle's four numerics modes: the checker's
+    adversarial rays (ground-sphere re-hits, grazing rays and rays leaving small spheres) single out exactly that mode, and every other
+    item is then predicted in it (ALL PASS).  This is what decides the library's default on the first Julia box."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_julia_kat.py")
+    r = subprocess.run([sys.executable, tool, "--self-test", "--numerics", mode, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ALL PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert f"as the oracle's `{mode}` mode" in r.stdout
+    line = next(x for x in r.stdout.splitlines() if x.startswith("numerics of hit(::Sphere{Float32})"))
+    counts = {m: tuple(int(v) for v in c.split("/")) for m, c in (part.strip().rsplit(" ", 1) for part in line.split("reproduced:", 1)[1].split(","))}
+    assert counts[mode][0] == counts[mode][1] and all(c[0] <= c[1] - 20 for m, c in counts.items() if m != mode), counts     # every other mode misses >= 20 rays
+
+
 def test_c_host_example_compiles_and_links(tmp_path):
     """include/rtw_hip.h is plain C99 and examples/render_c.c links against the built library (no GPU needed for that)"""
     import subprocess

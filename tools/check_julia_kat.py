@@ -8,6 +8,12 @@ hold.  If every RNG item passes, `--accept` renames tests/golden/rng_provisional
 
     python tools/check_julia_kat.py --self-test     # no Julia here: write the file the ORACLE predicts,
                                                     # then check it (exercises the parser; all items pass)
+    python tools/check_julia_kat.py --self-test --numerics contract    # ... as a Julia whose hit(::Sphere) evaluates the discriminant in
+                                                    # another of the oracle's numerics modes would print it: the checker must NAME that mode
+
+Round 5: the `adv` records (4096 rays leaving computed hit points on the r = 1000 ground sphere) decide WHICH evaluation order of
+src/hit.jl:16-18 the Julia build emits -- the oracle's `reference` (default of the library), `reference_fma`, `reference_fma2` or
+`contract`; the summary names the mode(s) that reproduce every record and says what to change if it is not the default.
 """
 import os
 import sys
@@ -87,8 +93,62 @@ def cameras(T):
     return (("t_default_cam", R.t_default_cam(elem_type=T)), ("t_cam1", R.t_cam1(elem_type=T)), ("t_cam2", R.t_cam2(elem_type=T)))
 
 
-def predicted_lines(outdir):
-    """What julia_kat.jl prints if every assumption of the oracle is right."""
+NUMERICS_MODES = ("reference", "reference_fma", "reference_fma2", "contract")
+
+
+def adv_inputs(T, n=4096):
+    """The self-test's own adversarial rays (julia_kat.jl 4c prints ITS inputs -- sphere, origin, direction --; the checker never has to
+    reproduce a recipe): first half rays leaving computed hit points on the r = 1000 ground sphere, then near-grazing rays at spheres of
+    radius 0.05 ... 0.45 and rays leaving computed hit points on such spheres.  -> [(c, r, o, d) | None]"""
+    rng = np.random.default_rng(20260929)
+    gc, gr = np.array([0, -1000, -1], T), T(1000)
+    out = []
+    with O.numerics("reference"):
+        for k in range(n // 2):
+            tgt = np.array([rng.uniform(-11, 11), 0, rng.uniform(-11, 11)], T)
+            d = normalize((tgt - np.array([13, 2, 3], T)).astype(T))
+            h = O.hit_sphere(gc, gr, np.array([13, 2, 3], T), d, T(1e-4), np.inf, T)
+            if h is None:
+                out.append(None); continue
+            u = rng.uniform(-1, 1, 3).astype(T)
+            nrm = np.asarray(h["n"], T)
+            d2 = normalize(np.array([nrm[0] + T(0.98) * u[0], nrm[1] + T(0.98) * u[1], nrm[2] + T(0.98) * u[2]], T))
+            out.append((gc, gr, np.asarray(h["p"], T), d2))
+    for k in range(n // 2, n):
+        c = np.array([rng.uniform(-11, 11), 0.2, rng.uniform(-11, 11)], T)
+        o = np.array([rng.uniform(-12, 12), rng.uniform(0.05, 3.05), rng.uniform(-12, 12)], T)
+        w = rng.uniform(-1, 1, 3).astype(T)
+        rr = T(rng.uniform(0.05, 0.45))
+        d1 = normalize(((c - o) + T(0.95) * rr * w).astype(T))
+        if k < 3 * n // 4:
+            out.append((c, rr, o, d1))
+            continue
+        with O.numerics("reference"):                               # last quarter: rays LEAVING the computed hit point on that small sphere
+            h = O.hit_sphere(c, rr, o, d1, T(1e-4), np.inf, T)
+        if h is None:
+            out.append(None); continue
+        u = rng.uniform(-1, 1, 3).astype(T)
+        nrm = np.asarray(h["n"], T)
+        out.append((c, rr, np.asarray(h["p"], T), normalize(np.array([nrm[0] + T(0.98) * u[0], nrm[1] + T(0.98) * u[1], nrm[2] + T(0.98) * u[2]], T))))
+    return out
+
+
+def adv_answer(c, r, o, d, T, mode):
+    with O.numerics(mode):
+        h = O.hit_sphere(c, r, o, d, T(1e-4), np.inf, T)
+    return "miss" if h is None else fmt(h["t"], T)
+
+
+def predicted_lines(outdir, numerics="reference"):
+    """What julia_kat.jl prints if every assumption of the oracle is right (and hit(::Sphere) evaluates in `numerics`)."""
+    prev = O.set_numerics(numerics)
+    try:
+        return _predicted_lines(outdir, numerics)
+    finally:
+        O.set_numerics(prev)
+
+
+def _predicted_lines(outdir, numerics):
     out = ["julia_version: (oracle self-test) nthreads: 1"]
     for seed in (1, 2):
         st = O.rng_seed(seed)
@@ -133,11 +193,37 @@ def predicted_lines(outdir):
                 h2 = O.hit_sphere(gc, gr, np.asarray(h["p"], T), normalize(np.array([n[0] + u[0], n[1] + u[1], n[2] + u[2]], T)), T(1e-4), np.inf, T)
                 outs.append("miss" if h2 is None else fmt(h2["t"], T))
             out.append(f"selfhit {name} {k}: " + " ".join(fmt(x, T) for x in (h["t"], *h["p"])) + " -> " + " ".join(outs))
+        for k, inp in enumerate(adv_inputs(T)):
+            if inp is None:
+                out.append(f"adv {name} {k}: primary miss"); continue
+            c, r, o, d2 = inp
+            out.append(f"adv {name} {k}: " + " ".join(fmt(x, T) for x in (*c, r, *o, *d2)) + " -> " + adv_answer(c, r, o, d2, T, numerics))
         img, _ = O.render(R.flatten_scene(R.scene_2_spheres(elem_type=T), T), R.t_default_cam(elem_type=T), 96, 54, 16, T=T, max_depth=16,
-                          rng_mode=O.REF_SERIAL, ref_threads=1, product_order=O.PRODUCT_REFERENCE)
+                          rng_mode=O.REF_SERIAL, ref_threads=1, product_order=O.PRODUCT_REFERENCE, numerics=numerics)
         np.ascontiguousarray(img.transpose(1, 0, 2)).astype(T).tofile(os.path.join(outdir, f"julia_render_2spheres_96x54_16spp_{name}.bin"))
         out.append(f"render {name} mean: " + fmt(img.astype(T).mean(dtype=np.float64), T))
     return out
+
+
+def classify_numerics(got):
+    """Which numerics mode(s) of the oracle reproduce EVERY `adv` record of a dump?  -> {T name: {mode: (matching, total)}}"""
+    res = {}
+    for name, T in TS.items():
+        recs = [(k, v) for k, v in got.items() if k.startswith(f"adv {name} ") and "->" in v]
+        if not recs:
+            continue
+        counts = {m: 0 for m in NUMERICS_MODES}
+        for _, v in recs:
+            lhs, rhs = v.split("->")
+            x = [T(t) for t in lhs.split()]
+            c, r, p, d = np.array(x[:3], T), x[3], np.array(x[4:7], T), np.array(x[7:10], T)
+            rhs = rhs.strip()
+            for m in NUMERICS_MODES:
+                a = adv_answer(c, r, p, d, T, m)
+                if a == rhs or (a != "miss" and rhs != "miss" and T(a) == T(rhs)):
+                    counts[m] += 1
+        res[name] = {m: (c, len(recs)) for m, c in counts.items()}
+    return res
 
 
 def check(path):
@@ -147,11 +233,38 @@ def check(path):
         if ":" in line:
             k, v = line.split(":", 1)
             got[k.strip()] = v.strip()
+    # round 5: first find out in which numerics mode this Julia evaluates hit(::Sphere); everything downstream (hit / selfhit records,
+    # the -t1 render) is then predicted in that mode
+    cls = classify_numerics(got)
+    mode = "reference"
+    verdicts = []
+    for name, counts in cls.items():
+        full = [m for m, (c, n) in counts.items() if c == n]
+        print(f"numerics of hit(::Sphere{{{name}}}) -- adversarial rays reproduced: " + ", ".join(f"{m} {c}/{n}" for m, (c, n) in counts.items()))
+        verdicts.append((name, full))
+    f32 = dict(verdicts).get("Float32")
+    if f32 is not None:
+        if len(f32) == 1:
+            mode = f32[0]
+            print(f"  -> this Julia evaluates src/hit.jl:16-18 as the oracle's `{mode}` mode" + (" (the library's default)" if mode == "reference" else
+                  f": make it the default (include/rtw_hip.h RTW_FLAG_NUMERICS_*; `numerics` of render()), or pass numerics={mode!r}"
+                  + (" -- the device does not implement reference_fma2 yet: sphere_disc needs r next to r^2" if mode == "reference_fma2" else "")))
+        elif not f32:
+            print("  -> NO numerics mode of the oracle reproduces every record: inspect julia_hit_sphere_Float32.ll (fmuladd? contract flags? a reassociated dot?)")
+        else:
+            mode = f32[0]
+            print(f"  -> not decided by these rays ({', '.join(f32)} all reproduce them)")
+    for name in TS:
+        ll = os.path.join(base, f"julia_hit_sphere_{name}.ll")
+        if os.path.exists(ll):
+            txt = open(ll).read()
+            print(f"  {os.path.basename(ll)}: fmul {txt.count('fmul')}, fadd {txt.count('fadd')}, fsub {txt.count('fsub')}, llvm.fmuladd {txt.count('llvm.fmuladd')}, "
+                  f"llvm.fma {txt.count('llvm.fma.')}, `contract`/`fast` flags {txt.count(' contract ') + txt.count(' fast ')}, llvm.powi {txt.count('llvm.powi')}")
     want = {}
-    for line in predicted_lines("/tmp"):
+    for line in predicted_lines("/tmp", mode):
         k, v = line.split(":", 1)
         want[k.strip()] = v.strip()
-    items = []
+    items = [(f"numerics mode of hit(::Sphere) identified ({mode})", f32 is None or len(f32) == 1, "src/hit.jl:16-18", [], [])]
 
     def item(name, keys, why, numeric_T=None):
         ks = [k for k in want if any(k.startswith(p) for p in keys)]
@@ -181,6 +294,7 @@ def check(path):
         item(f"tand {name}", [f"tand {name}"], "src/camera.jl:23", T)
         item(f"hit(::Sphere) {name} (@fastmath contraction of the discriminant)", [f"hit {name}"], "src/hit.jl:12-35", T)
         item(f"tmin self-intersection on the r = 1000 ground sphere {name}", [f"selfhit {name}"], "src/ray_color.jl:19, src/hit.jl:19-29", T)
+        item(f"adversarial ground-sphere rays {name} (in the identified mode)", [f"adv {name}"], "src/hit.jl:16-18", T)
     # a failing seed expansion: say WHICH expansion Julia uses (two are plausible; the package source is not in the reference tree)
     for seed in (1, 2):
         k = f"rng_state seed={seed}"
@@ -202,7 +316,7 @@ def check(path):
             continue
         jl = np.fromfile(f, dtype=T).reshape(96, 54, 3).transpose(1, 0, 2)
         ref, _ = O.render(R.flatten_scene(R.scene_2_spheres(elem_type=T), T), R.t_default_cam(elem_type=T), 96, 54, 16, T=T, max_depth=16,
-                          rng_mode=O.REF_SERIAL, ref_threads=1, product_order=O.PRODUCT_REFERENCE)
+                          rng_mode=O.REF_SERIAL, ref_threads=1, product_order=O.PRODUCT_REFERENCE, numerics=mode)
         same = np.array_equal(jl, ref)
         d = np.abs(jl.astype(np.float64) - ref.astype(np.float64))
         print(f"{'render(scene_2_spheres, default cam, 96, 16), julia -t1 vs oracle REF_SERIAL ' + name:72s} "
@@ -215,10 +329,13 @@ def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
     if sys.argv[1] == "--self-test":
-        d = sys.argv[2] if len(sys.argv) > 2 else "/tmp/julia_kat_selftest"
+        rest = [a for a in sys.argv[2:] if not a.startswith("--")]
+        numerics = sys.argv[sys.argv.index("--numerics") + 1] if "--numerics" in sys.argv else "reference"
+        rest = [a for a in rest if a != numerics]
+        d = rest[0] if rest else "/tmp/julia_kat_selftest"
         os.makedirs(d, exist_ok=True)
         path = os.path.join(d, "julia_kat.txt")
-        open(path, "w").write("\n".join(predicted_lines(d)) + "\n")
+        open(path, "w").write("\n".join(predicted_lines(d, numerics)) + "\n")
         items = check(path)
     else:
         items = check(sys.argv[1])

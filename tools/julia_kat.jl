@@ -14,9 +14,14 @@
 #   4b. the tmin self-intersection regime on the r = 1000 ground sphere (src/ray_color.jl:19: tmin = T(1e-4) is the size of a binary32
 #       ulp there -- it is what makes Float32 take 3.94 segments per sample against 2.71 in Float64): rays that LEAVE a computed hit
 #       point on the ground sphere, steep to grazing, and whether hit(ground, ...) finds the far root again
+#   4c. WHICH evaluation of src/hit.jl:16-18 this Julia build emits (round 5): 4096 rays that leave computed hit points on the r = 1000
+#       ground sphere (inputs printed, so the checker evaluates exactly these) -- the oracle's numerics modes `reference` (StaticArrays'
+#       un-fused dot, one rounding per operation), `reference_fma` (disc = fma(half_b, half_b, -c)), `reference_fma2` (... and
+#       c = fma(-r, r, oc.oc)) and `contract` (three FMA chains) disagree on a few per cent of them -- plus the LLVM IR and the native code of
+#       hit(::Sphere{Float32}, ...) in julia_hit_sphere_Float32.ll / .s (look for fmuladd / contract flags / vfmadd)
 #   5. render(scene_2_spheres, default cam, 96, 16) with ONE thread (the reference's own smoke
 #      render, test/runtests.jl:194) -> compare with the oracle's REF_SERIAL, ref_threads = 1
-using RayTracingWeekend, StaticArrays, RandomNumbers.Xorshifts, Printf
+using RayTracingWeekend, StaticArrays, RandomNumbers.Xorshifts, Printf, InteractiveUtils
 
 fmt(x::Float32) = @sprintf("%.9g", x)
 fmt(x::Float64) = @sprintf("%.17g", x)
@@ -77,6 +82,47 @@ for T in (Float32, Float64)
             push!(outs, rec2 === nothing ? "miss" : fmt(rec2.t))
         end
         println("selfhit $T $k: ", vals((rec.t, rec.p...)), " -> ", join(outs, " "))
+    end
+    # 4c: adversarial rays for the evaluation order of the discriminant.  A 64-bit LCG (wrapping UInt64 arithmetic) picks points and
+    # directions; EVERY value that enters hit() is printed (sphere, origin, direction): the checker does not have to reproduce this recipe.
+    # Records 0 - 2047: rays leaving computed hit points on the r = 1000 ground sphere (the consequential regime: contract vs the rest);
+    # 2048 - 3071: near-grazing rays at spheres of radius 0.05 ... 0.45; 3072 - 4095: rays leaving computed hit points on such spheres (r^2 is
+    # inexact and c ~ 0 there: separates reference / reference_fma / reference_fma2).
+    let st = UInt64(12345)
+        nextu() = (st = st * 0x5851f42d4c957f2d + 0x14057b7ef767814f; T((st >> 40) % 0x100000) / T(0x100000))       # 20 bits: exact in Float32
+        adv(k, sp, o, d) = begin
+            rec2 = RayTracingWeekend.hit(sp, RayTracingWeekend.Ray(o, d), T(1e-4), typemax(T))
+            println("adv $T $k: ", vals((sp.center..., sp.radius, o..., d...)), " -> ", rec2 === nothing ? "miss" : fmt(rec2.t))
+        end
+        for k in 0:2047
+            tgt = SA{T}[T(-11) + T(22) * nextu(), T(0), T(-11) + T(22) * nextu()]
+            rec = RayTracingWeekend.hit(ground, RayTracingWeekend.Ray(SA{T}[13, 2, 3], normalize(tgt - SA{T}[13, 2, 3])), T(1e-4), typemax(T))
+            u = SA{T}[T(2) * nextu() - T(1), T(2) * nextu() - T(1), T(2) * nextu() - T(1)]
+            rec === nothing && (println("adv $T $k: primary miss"); continue)
+            adv(k, ground, rec.p, normalize(rec.n⃗ + T(0.98) * u))
+        end
+        for k in 2048:4095
+            c = SA{T}[T(-11) + T(22) * nextu(), T(0.2), T(-11) + T(22) * nextu()]
+            rr = T(0.05) + T(0.4) * nextu()                           # (a radius whose square is not exact: separates c = oc.oc - r^2 from fma(-r, r, oc.oc))
+            sp = Sphere(c, rr, Lambertian(SA{T}[0.5, 0.5, 0.5]))
+            o = SA{T}[T(-12) + T(24) * nextu(), T(0.05) + T(3) * nextu(), T(-12) + T(24) * nextu()]
+            w = SA{T}[T(2) * nextu() - T(1), T(2) * nextu() - T(1), T(2) * nextu() - T(1)]
+            d1 = normalize((c - o) + T(0.95) * rr * w)                # aimed at the sphere, missing its centre by up to its radius
+            if k < 3072
+                adv(k, sp, o, d1)
+            else                                                       # 3072 - 4095: rays LEAVING the computed hit point on that small sphere (c = oc.oc - r^2 is ~ 0:
+                rec = RayTracingWeekend.hit(sp, RayTracingWeekend.Ray(o, d1), T(1e-4), typemax(T))      #  the rounding of r^2 decides: reference_fma vs reference_fma2)
+                rec === nothing && (println("adv $T $k: primary miss"); continue)
+                u = SA{T}[T(2) * nextu() - T(1), T(2) * nextu() - T(1), T(2) * nextu() - T(1)]
+                adv(k, sp, rec.p, normalize(rec.n⃗ + T(0.98) * u))
+            end
+        end
+    end
+    open("julia_hit_sphere_$(T).ll", "w") do io
+        code_llvm(io, RayTracingWeekend.hit, (Sphere{T}, RayTracingWeekend.Ray{T}, T, T); debuginfo=:none)
+    end
+    open("julia_hit_sphere_$(T).s", "w") do io
+        code_native(io, RayTracingWeekend.hit, (Sphere{T}, RayTracingWeekend.Ray{T}, T, T); debuginfo=:none)
     end
     Threads.nthreads() == 1 || @warn "run with -t1: the image depends on the thread count (SURVEY F6)"
     img = render(scene_2_spheres(elem_type=T), default_camera(SA{T}[0, 0, 0]), 96, 16)
