@@ -522,7 +522,7 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
     //   |c|^2)]; d(nc) <= u [4.01 r^2 + 6.02 |oc|^2 + 2.01 (|o|^2 + |c|^2)]; the two final roundings <= u [2 r^2 +
     //   3.01 |oc|^2 + 2 G]; |o|^2 <= 2 |oc|^2 + 2 |c|^2).  2^-18 = 64 u > 28.5 u, and the upload sets
     //   G = 1.01 (2^-18 r^2 + 2^-20 |c|^2 + 2^-20 r^2) + 1e-30 (rounded up), so  disc >= 0  =>  W > 0: sign bit clear.
-    //   The binary64 roundings of the contract itself (<= 20 * 2^-53 (|oc| + r)^2) vanish in the slack.  Rays that
+    //   The binary64 roundings of the deciding discriminant itself (<= 20 * 2^-53 (|oc| + r)^2 in every numerics mode) vanish in the slack.  Rays that
     //   are not (nearly) unit, not finite or astronomically far take every sphere as a candidate (lane_ok).
     [[maybe_unused]] bool lane_ok = true;
     [[maybe_unused]] V3<float> of = {0, 0, 0}, df = {0, 0, 1};
@@ -635,10 +635,11 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 // instruction per (ray, sphere) -- the v_alignbit that collects the sign -- instead of the 11 instructions of hit_world's
 // pass 1 (round 2 formed W = P1^2 + P2 from two separate products: one v_fma_f32 more per test, 22 % of the kernel's VALU
 // instructions, and 16 more result registers).  An MFMA and VALU instructions do not overlap on a SIMD, whichever wave they
-// come from and however they are interleaved (tools/ubench_mfma_overlap.hip, tools/ubench_mfma_pipe.hip): the scan costs
+// come from and however they are interleaved (tools/ubench_mfma_overlap.hip, tools/ubench_mfma_pipe.hip; in the kernel itself:
+// every MFMA pair executed twice / three times costs +38 % / +80 %, profiles/r05_probe_phases.txt): the scan costs
 // the SUM of its MFMA and VALU issue time, so the instruction count is what there is to gain.
-// The result is only a FILTER, like the binary32 filter of hit_world<double>: pass 2 applies the exact contract test to
-// every candidate, so pass 1 must flag a SUPERSET of {contract discriminant >= 0}.
+// The result is only a FILTER, like the binary32 filter of hit_world<double>: pass 2 applies the exact test of the render's numerics
+// mode (sphere_disc) to every candidate, so pass 1 must flag a SUPERSET of {deciding discriminant >= 0} for every mode.
 // Precision.  Every f32 feature x is split into two f16 pieces x = p1 + p2 + e, |e| <= eta |x| + phi (eta = 2^-22; phi = 2^-25:
 // the floor once a piece is an f16 subnormal -- the instruction honours subnormal inputs, tools/ubench_mfma_f16_numerics.hip)
 // and three K slots hold the cross terms a1 b1, a1 b2, a2 b1 of a feature pair (a2 b2 <= 2^-22 |a b| is dropped), so every
@@ -661,15 +662,20 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
 //     q computed in binary32 (3.01 u |o|) against 2 |hb| <= 2.001 (|o| + |c|)            3.01 (|o|^2 + |o| |c|)
 //     |o|^2, q^2 and the fma that forms q^2 - oo' in binary32                          1.3 |o|^2
 //     two MFMAs, beta x (sum |terms| + |C|)                     12.01 |c|^2 + 8.01 |o| |c| + 4.01 |o|^2 + 4 r^2 + 4 Gs
-//     contract discriminant vs exact arithmetic (binary32)   15 u |o - c|^2 + 4 u r^2   3.75 S + r^2
+//     the deciding discriminant vs exact arithmetic (binary32), in EVERY numerics mode (sphere_disc_n):          4.28 S + r^2
+//         contract form (three FMA chains)          15 u |o - c|^2 + 4 u r^2
+//         reference order (round 5, the default)    17.2 u |o - c|^2 + 3.1 u r^2:  with e = o - c and e^ its rounded components (u |e_k| each),
+//             half_b = fl(fl(fl(e1 d1) + fl(e2 d2)) + fl(e3 d3)) is within 3 u |e||d| of e^.d and e^.d within u |e||d| of e.d: 4.01 u |e|; its square
+//             8.06 u |e|^2 + the rounding of the product 1.01 u |e|^2 (absent with disc = fma(half_b, half_b, -c)); oc.oc 3 u |e|^2 + 2.01 u |e|^2;
+//             r r: u r^2;  c = fl(oc.oc - r^2): 1.01 u (|e|^2 + r^2);  disc = fl(half_b^2 - c): 2.03 u |e|^2 + 1.01 u r^2
 //     inputs rounded from binary64 (hit_world_mfma<double>)                            1.5 S
-// With |o| |c| <= (|o|^2 + |c|^2) / 2 and S <= 2 |o|^2 + 2 |c|^2:  E <= 2^-22 (34.8 |c|^2 + 27.6 |o|^2 + 5 r^2) + floors,
+// With |o| |c| <= (|o|^2 + |c|^2) / 2 and S <= 2 |o|^2 + 2 |c|^2:  E <= 2^-22 (35.9 |c|^2 + 28.7 |o|^2 + 5 r^2) + floors,
 // floors <= phi_c (5.5 |o|_1 + |c|_1) + 1.4 phi_k, phi_c = 2^-25 / s (second pieces of the linear features; |p|_1 <= 2.74 |o|_1),
 // phi_k = 2^-20 / s^2 (the 2^4-scaled pieces of k' and q^2 - oo', the quadratic features' second pieces).  The margin separates:
 // the upload adds  Gs = 1.02 [(2 A_S + A_r)|c|^2 + A_r r^2 + 9 phi_c |c|_1 + 1.5 phi_k]  to k' (A_S = 32 x 2^-22 = 2^-17, A_r = 12 x
-// 2^-22: the round-2 constants, kept although this formulation needs only 35 / 28 / 5 of the 76 / 64 / 12 they provide -- no
+// 2^-22: the round-2 constants, kept although this formulation needs only 36 / 29 / 5 of the 76 / 64 / 12 they provide -- no
 // error is amplified by a squaring any more) and the ray subtracts  oo' = |o|^2 (1 - 1.02 x 2^-16) - 9.18 phi_c |o|_1
-// (mf_oo_keep, mf_o1_coef), so that  contract discriminant >= 0  =>  W > 0: sign bit clear.
+// (mf_oo_keep, mf_o1_coef), so that  deciding discriminant >= 0 (any numerics mode)  =>  W > 0: sign bit clear.
 // Rays that are not (nearly) unit (the reference does not renormalise dielectric reflections), not finite, or farther
 // than 2^13 / s from the origin take EVERY sphere as a candidate (all features 0, t1 = 60000); lanes without a ray take none
 // (t1 = -60000).  Padding spheres carry k' s^2 = -2^30.
@@ -1183,7 +1189,8 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
 //     test of its RAY (t >= 0) against every cluster box, the box inflated per ray by
 //         m = kappa * (|o - Cs| + Rs + 1),   kappa = 2^-8 (Float32) / 2^-22 (Float64).
 //     Why this is conservative: sphere_root accepts sphere i only if its contract discriminant is
-//     >= 0, and |disc_c - D| <= 20u (|o-c_i| + r_i)^2, so the line passes within
+//     >= 0, and |disc_c - D| <= 20u (|o-c_i| + r_i)^2 in every numerics mode (17.2 u |o-c|^2 + 3.1 u r^2 for the reference's un-fused
+//     order, see hit_world_mfma), so the line passes within
 //     r_i + 4.5 sqrt(u) (|o-c_i| + r_i) <= r_i + m/2 of c_i; an accepted root is >= tmin > 0, so
 //     either the closest approach is in front of the origin (that point is inside the box grown
 //     by m/2) or the origin itself is within r_i + m/2 of c_i.  The slab arithmetic adds

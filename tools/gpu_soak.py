@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak test of the matrix-pipe filter: random scans (unit ops 13 and 14 vs the oracle) with fresh seeds for a
-given number of seconds, then random small renders in every scan mode vs the oracle.
+given number of seconds, then random small renders in every scan mode vs the oracle; the numerics mode of the ray-sphere test
+(reference / contract / reference_fma) changes with the seed, on both sides.
 usage: python tools/gpu_soak.py [seconds=300] [first_seed=1000]   (needs the GPU; prints one summary line per part)
 A 60-second slice of the same two loops gates the GPU suite: tests/test_gpu_round3.py::test_soak_slice."""
 import os, sys, time
@@ -9,6 +10,17 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 import numpy as np
+
+NUMERICS = ("reference", "contract", "reference_fma")      # the numerics mode of a round follows its seed: all three are soaked
+
+
+def _set_numerics(seed):
+    """both sides -- the oracle and the product's Python mirror -- to the mode of this seed; returns (mode, restore())"""
+    import rtw_oracle as O
+    from rtw_amd import _capi
+    mode = NUMERICS[(seed // 2) % 3]
+    prev = (O.set_numerics(mode), _capi.set_default_numerics(mode))
+    return mode, (lambda: (O.set_numerics(prev[0]), _capi.set_default_numerics(prev[1])))
 
 
 def scan_rounds(seconds, seed, log=print, max_rounds=None):
@@ -22,6 +34,7 @@ def scan_rounds(seconds, seed, log=print, max_rounds=None):
     while time.time() - t0 < seconds and (max_rounds is None or rounds < max_rounds):
         rng = np.random.default_rng(seed)
         T = np.float32 if seed % 2 == 0 else np.float64
+        mode, restore = _set_numerics(seed)
         n = int(rng.choice([1, 2, 7, 33, 64, 65, 200, 485, 600, 1500]))
         scale = float(rng.choice([1e-3, 0.1, 1, 10, 12, 100, 1e3, 1e4, 1e6]))
         m = 131072
@@ -35,7 +48,8 @@ def scan_rounds(seconds, seed, log=print, max_rounds=None):
             bad = (y[:, 0].astype(np.int64) != ref_idx) | ((ref_idx >= 0) & (y[:, 1] != ref_t.astype(np.float64)))
             rays_total += m; bad_total += int(bad.sum())
             if bad.any():
-                log(f"MISMATCH op {op} seed {seed} n {n} scale {scale} T {T.__name__}: {int(bad.sum())} rays, first {np.flatnonzero(bad)[:5]}")
+                log(f"MISMATCH op {op} seed {seed} numerics {mode} n {n} scale {scale} T {T.__name__}: {int(bad.sum())} rays, first {np.flatnonzero(bad)[:5]}")
+        restore()
         rounds += 1
         seed += 1
     return rounds, rays_total, bad_total, seed
@@ -54,6 +68,7 @@ def render_rounds(seconds, seed, log=print, max_rounds=None):
     while time.time() - t0 < seconds and (max_rounds is None or scenes < max_rounds):
         rng = np.random.default_rng(seed)
         T = np.float32 if seed % 2 == 0 else np.float64
+        mode, restore = _set_numerics(seed)
         n = int(rng.choice([3, 20, 100, 485]))
         scale = float(rng.choice([0.5, 1, 4, 30]))
         flat = dict(n=n, cx=(rng.uniform(-4, 4, n) * scale).astype(T), cy=(rng.uniform(-2, 2, n) * scale).astype(T),
@@ -71,7 +86,8 @@ def render_rounds(seconds, seed, log=print, max_rounds=None):
             imgs += 1
             if not (np.array_equal(img, ref, equal_nan=True) and st.segments == ost["segments"]):
                 bad_imgs += 1
-                log(f"IMAGE MISMATCH seed {seed} n {n} scale {scale} flags {flags}: {(img != ref).sum()} channels")
+                log(f"IMAGE MISMATCH seed {seed} numerics {mode} n {n} scale {scale} flags {flags}: {(img != ref).sum()} channels")
+        restore()
         seed += 1
         scenes += 1
     return imgs, bad_imgs, seed
