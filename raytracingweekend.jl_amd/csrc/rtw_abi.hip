@@ -11,7 +11,7 @@
 
 namespace rtwh {
 
-thread_local char g_err[512] = "";
+__thread char g_err[512] = "";
 
 // Measurement / test switches of the environment are honoured only under the master switch RTW_ENABLE_TEST_AIDS=1 (read once):
 // without it a stray RTW_SCAN=valu or RTW_JOB_PIXELS=1 in a caller's environment changes nothing (include/rtw_hip.h).

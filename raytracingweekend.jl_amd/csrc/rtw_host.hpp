@@ -60,7 +60,7 @@ struct rtw_scene_dev {
 
 namespace rtwh {
 
-extern thread_local char g_err[512];
+extern __thread char g_err[512];         // (__thread: no dynamic initialisation, so no init-function call through a hidden weak symbol from the other translation units)
 int fail(int code, const char *fmt, ...);
 
 // Measurement / test switches of the environment are honoured only under the master switch RTW_ENABLE_TEST_AIDS=1 (read once):

@@ -170,10 +170,10 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
     // (RCCL: the communicator set of this device list, locked for this render until its streams have drained -- RcclSet, rtw_multi.hip)
     std::shared_ptr<RcclSet> rccl_set;
     std::unique_lock<std::mutex> rccl_use;
-    if (use_rccl) { if (int rc = rccl_acquire(devs, &rccl_set, &rccl_use)) return rc; }
     std::vector<HostLease> L(N);
     for (int r = 0; r < N; ++r)
         if (int rc = acquire_host(devs[r], key, &L[r])) return fail(rc, "device %d (shard %d of %d): %s", devs[r], r, N, std::string(g_err).c_str());
+    if (use_rccl) { if (int rc = rccl_acquire(devs, &rccl_set, &rccl_use)) return rc; }       // (after the devices are known to exist; a host context is never waited for, so the order cannot deadlock)
     {   // scene uploads of the devices that do not have it yet, in parallel (a cache miss on 8 devices is 8 x (kd split + a dozen copies))
         std::vector<int> up_rc(N, 0);
         std::vector<std::string> up_err(N);

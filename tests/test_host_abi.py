@@ -60,6 +60,27 @@ def test_render_fails_loudly_without_gpu(rtw):
     scene = rtw.scene_2_spheres(elem_type=np.float32)
     with pytest.raises(RtwError, match="no HIP device|hip"):
         rtw.render(scene, rtw.t_default_cam(), 96, 1)
+    # every entry point's error path, not only the one-device one (round 5: the device-list path read the thread-local error text from
+    # another translation unit through an init function that hidden visibility had resolved to address 0 -- a crash instead of an error)
+    with pytest.raises(RtwError, match="no HIP device|hip|device"):
+        rtw.render(scene, rtw.t_default_cam(), 96, 1, devices=[0, 4096])
+    with pytest.raises(RtwError, match="no HIP device|hip|device"):
+        rtw.render(scene, rtw.t_default_cam(), 96, 1, devices="all")
+    with pytest.raises(RtwError, match="no HIP device|hip|device|rccl"):
+        rtw.render(scene, rtw.t_default_cam(), 96, 1, devices=[0], rccl_reduce=True)
+    from rtw_amd import _capi
+    import ctypes as C
+    st = _capi.Stats()
+    assert _capi.lib().rtw_stats(C.byref(st)) != 0 and b"render" in _capi.lib().rtw_last_error()
+
+
+def test_library_has_no_unresolved_internal_symbols():
+    """the library is built from several translation units with hidden visibility: nothing of namespace rtwh may be left undefined
+    (an undefined hidden weak symbol is called as address 0)"""
+    import subprocess
+    from rtw_amd import _capi
+    out = subprocess.run(["nm", "--undefined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rtwh" not in out and "N3rtw" not in out, [ln for ln in out.splitlines() if "rtw" in ln]
 
 
 def test_render_argument_validation(rtw):

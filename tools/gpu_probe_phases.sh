@@ -10,11 +10,12 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/probe
 declare -A FL=( [base]="" [mfma]="-DRTW_DUP_MFMA" [eval]="-DRTW_DUP_EVAL" [extract]="-DRTW_DUP_EXTRACT" [resolve]="-DRTW_DUP_RESOLVE_PAIRS" [reject]="-DRTW_DUP_REJECT" [noskip]="-DRTW_SCAN_SKIP=0" [rejcap3]="-DRTW_PROBE_REJ_CAP=3" [rejcap2]="-DRTW_PROBE_REJ_CAP=2" [cmp]="-DRTW_SCAN_CMP=1" [fastdiv]="-DRTW_PROBE_FASTDIV" [operands]="-DRTW_DUP_OPERANDS" [noaccum]="-DRTW_PROBE_NO_ACCUM" [mfma2]="-DRTW_DUP_MFMA=2" [nomfma]="-DRTW_PROBE_NO_MFMA" )
 NAMES=${@:-base mfma eval extract resolve reject noskip}
-for n in $NAMES; do make -s -C raytracingweekend.jl_amd/csrc -B OUT=/tmp/librtw_p_$n.so EXTRA="${FL[$n]}" 2>&1 | grep -E "error"; done
+echo "== ${DT:-f32} ${WIDTH:-1920} x ${SPP:-200} spp, depth ${DEPTH:-50}"
+for n in $NAMES; do [ -f /tmp/librtw_p_$n.so ] || make -s -j8 -C raytracingweekend.jl_amd/csrc -B OUT=/tmp/librtw_p_$n.so OBJDIR=/tmp/obj_p_$n EXTRA="${FL[$n]}" 2>&1 | grep -E "error"; done
 for n in $NAMES; do
   O=$R/gpurun_out/probe/$n; rm -rf $O; mkdir -p $O
-  (cd /tmp && TMPDIR=/tmp RTW_HIP_LIB=/tmp/librtw_p_$n.so rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O -o p -- python $R/tools/gpu_quick.py ${DT:-f32} 1920 ${SPP:-200} 50 plain 1 > $O/log.txt 2>&1)
-  RTW_HIP_LIB=/tmp/librtw_p_$n.so python tools/gpu_quick.py ${DT:-f32} 1920 ${SPP:-200} 50 plain 3 2>/dev/null | grep kernel | tail -1 > $O/plain.txt
+  (cd /tmp && TMPDIR=/tmp RTW_HIP_LIB=/tmp/librtw_p_$n.so rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O -o p -- python $R/tools/gpu_quick.py ${DT:-f32} ${WIDTH:-1920} ${SPP:-200} ${DEPTH:-50} plain 1 > $O/log.txt 2>&1)
+  RTW_HIP_LIB=/tmp/librtw_p_$n.so python tools/gpu_quick.py ${DT:-f32} ${WIDTH:-1920} ${SPP:-200} ${DEPTH:-50} plain 3 2>/dev/null | grep kernel | tail -1 > $O/plain.txt
   python3 - <<PY
 import csv, glob, re
 c = {}

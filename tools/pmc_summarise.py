@@ -21,10 +21,16 @@ for d in sorted(glob.glob(O + "/pmc_*")):
     out[os.path.basename(d)] = {"counters": dict(c), "launches": len(dur), "kernel_ns": dur, "launches_in_pass": len(set(row["Dispatch_Id"] for row in rows))}
 # derived figures of the headline kernel: per wave-segment = per 64 ray segments (segments from the bench line of the same workload)
 try:
-    segs = 8177903451.0        # 1920 x 1080 x 1000 spp: the segments the kernel counts (rtw_stats_t.segments; 3.9438 per sample)
+    # 1920 x 1080 x 1000 spp: the segments the kernel counted in that pass (the bench line of the pass: it depends on the numerics mode --
+    # 4.119 per sample in the reference's evaluation order, 3.944 in the contract form of rounds 1-4)
+    def segs_of(tag):
+        line = [ln for ln in open(O + "/pmc_%s.log" % tag) if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return d["segments_per_sample"] * 1920 * 1080 * 1000, d.get("numerics")
+    segs, numerics = segs_of("f32_sqA")
     a, m = out["pmc_f32_sqA"]["counters"], out["pmc_f32_mfma"]["counters"]
     cyc = a["GRBM_GUI_ACTIVE"] / 8
-    out["derived_f32"] = {"valu_per_wave_segment": a["SQ_INSTS_VALU"] / (segs / 64), "mfma_per_wave_segment": m["SQ_INSTS_MFMA"] / (segs / 64),
+    out["derived_f32"] = {"numerics": numerics, "segments": segs, "valu_per_wave_segment": a["SQ_INSTS_VALU"] / (segs / 64), "mfma_per_wave_segment": m["SQ_INSTS_MFMA"] / (segs / 64),
                           "clock_GHz": cyc / out["pmc_f32_sqA"]["kernel_ns"][0], "mfma_busy_frac_of_simd_cycles": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc),
                           "valu_busy_frac_at_2_cycles": a["SQ_INSTS_VALU"] * 2 / (1024 * cyc), "wait_any_frac_of_wave_cycles": a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"]}
     wc = a["SQ_WAVE_CYCLES"]
@@ -40,6 +46,12 @@ try:
                                "wait_any_frac_of_wave_cycles": pa["SQ_WAIT_ANY"] / pa["SQ_WAVE_CYCLES"], "wait_inst_any_frac_of_wave_cycles": pa["SQ_WAIT_INST_ANY"] / pa["SQ_WAVE_CYCLES"],
                                "lds_bank_conflict_frac": pm_["SQ_LDS_BANK_CONFLICT"] / max(pm_["SQ_LDS_IDX_ACTIVE"], 1),
                                "salu_per_wave_segment_lane_loop": a["SQ_INSTS_SALU"] / (segs / 64), "lds_per_wave_segment_lane_loop": out["pmc_f32_sqB"]["counters"]["SQ_INSTS_LDS"] / (segs / 64)}
+    ca, cm = out.get("pmc_f32_cull_sqA"), out.get("pmc_f32_cull_mfma")
+    if ca and cm:
+        ca, cm, ccyc = ca["counters"], cm["counters"], ca["counters"]["GRBM_GUI_ACTIVE"] / 8
+        out["derived_f32_cull"] = {"valu_per_wave_segment": ca["SQ_INSTS_VALU"] / (segs / 64), "salu_per_wave_segment": ca["SQ_INSTS_SALU"] / (segs / 64),
+                                   "mfma_per_wave_segment": cm["SQ_INSTS_MFMA"] / (segs / 64), "clock_GHz": ccyc / out["pmc_f32_cull_sqA"]["kernel_ns"][0],
+                                   "mfma_busy_frac_of_simd_cycles": cm["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * ccyc), "valu_busy_frac_at_2_cycles": ca["SQ_INSTS_VALU"] * 2 / (1024 * ccyc)}
 except Exception as e:
     out.setdefault("derived_f32", {})["error"] = str(e)
 json.dump(out, open(O + "/pmc_summary.json", "w"), indent=1)
