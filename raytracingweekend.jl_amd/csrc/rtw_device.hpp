@@ -942,7 +942,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     // touches no block of it; a ray that does not use the filter (not ok) touches every block; the BIG class's blocks carry infinite
     // bounds (never skipped); lanes without a ray are masked out of the vote.
     [[maybe_unused]] float pming[3] = {0, 0, 0}, pmaxg[3] = {0, 0, 0};
-    [[maybe_unused]] unsigned long long ray_mask = 0;
+    [[maybe_unused]] unsigned long long ray_mask = 0, all_mask = 0;
     typedef const float __attribute__((address_space(4))) *cfptr;
     [[maybe_unused]] cfptr gbox = nullptr;
     if constexpr (CULLED) {
@@ -954,7 +954,11 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         //  points of the clip, whose rounding the 2 m of slack covers a thousandfold -- the IEEE forms cost 65 instructions per scan)
         const float m = 1.001f * (0.00390625f * (s2 > 1.0f ? s2 : 1.0f) + 2.0f * __builtin_amdgcn_sqrtf(eps_p)) *
                         ((__builtin_amdgcn_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) + mc->rs) + 1.0f);
-        auto safe_inv = [](float x) { const float e = 1e-9f; const float y = (x < e && x > -e) ? (x < 0.0f ? -e : e) : x; return __builtin_amdgcn_rcpf(y); };
+        // 1 / d_k with |d_k| clamped to >= 1e-9 (moves the ray by < 1e-9 t): max on the magnitude, the sign copied back (v_max_f32 |x|, v_bfi_b32, v_rcp_f32)
+        auto safe_inv = [](float x) {
+            const float mag = __builtin_fmaxf(__builtin_fabsf(x), 1e-9f);
+            return __builtin_amdgcn_rcpf(__uint_as_float((__float_as_uint(mag) & 0x7fffffffu) | (__float_as_uint(x) & 0x80000000u)));
+        };
         const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
         const float x0 = ((mc->glo[0] - m) - ox) * ix, x1 = ((mc->ghi[0] + m) - ox) * ix;
         const float y0 = ((mc->glo[1] - m) - oy) * iy, y1 = ((mc->ghi[1] + m) - oy) * iy;
@@ -964,13 +968,14 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         const float m2 = m + m;
         const float ax = __builtin_fmaf(tn, dx, ox), ay = __builtin_fmaf(tn, dy, oy), az = __builtin_fmaf(tn, dz, oz);
         const float bx = __builtin_fmaf(tf, dx, ox), by = __builtin_fmaf(tf, dy, oy), bz = __builtin_fmaf(tf, dz, oz);
-        const bool hits_class = !(tf < tn);                  // (a NaN anywhere: treated as "meets the class"; its bounds are then made infinite below)
-        const bool finite = (ax - ax) + (ay - ay) + (az - az) + (bx - bx) + (by - by) + (bz - bz) + (m - m) == 0.0f;
-        const float big = 3.0e38f, inf = __builtin_huge_valf();
+        // (for a ray that uses the filter every quantity above is finite: |o_k| <= mf_o_max, |d|^2 <= 1.0009, |1 / d_k| <= 1e9; the others are
+        //  handled by the mask below, whatever their bounds came out as)
+        const bool hits_class = tf >= tn;
+        const float big = 3.0e38f;
         pming[0] = __builtin_fminf(ax, bx) - m2; pming[1] = __builtin_fminf(ay, by) - m2; pming[2] = __builtin_fminf(az, bz) - m2;
         pmaxg[0] = __builtin_fmaxf(ax, bx) + m2; pmaxg[1] = __builtin_fmaxf(ay, by) + m2; pmaxg[2] = __builtin_fmaxf(az, bz) + m2;
         if (!hits_class) { pming[0] = pming[1] = pming[2] = big; pmaxg[0] = pmaxg[1] = pmaxg[2] = -big; }      // no block of the small class (the BIG class's bounds are +-inf: still touched)
-        if (!ok || !finite) { pming[0] = pming[1] = pming[2] = -inf; pmaxg[0] = pmaxg[1] = pmaxg[2] = inf; }    // every block
+        all_mask = __ballot(has_ray && !ok);                 // rays that do not use the filter touch EVERY block
     }
     uint4 A1 = pa[0], A2 = pa[64];
     // Wave priority: low inside the block loop, raised for everything else (pass 2 and the divergent phases of the lane loop are
@@ -989,7 +994,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             // (the block's bounds are stored grown by nothing; m is on the ray's side: pming / pmaxg)
             const float sep = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lx - pmaxg[0], ly - pmaxg[1]), lz - pmaxg[2]),
                                               __builtin_fmaxf(__builtin_fmaxf(pming[0] - hx, pming[1] - hy), pming[2] - hz));
-            const unsigned long long touch = __ballot(!(sep > 0.0f)) & ray_mask;
+            const unsigned long long touch = (__ballot(!(sep > 0.0f)) & ray_mask) | all_mask;
             clk.count(7, 1u);
             if (!touch) {
                 clk.count(6, 1u);
