@@ -709,10 +709,19 @@ struct WaveScratch {
 };
 
 // x = p1 + p2 with p1 = RN16(x), p2 = RN16(x - p1); returns p1 | p2 << 16
+// Two instructions: v_cvt_f16_f32 writes p1 to the low half, v_fma_mixhi_f16 computes x * 1.0 - p1 with the f16 operand read in place
+// (exact in binary32: p1 is x rounded to 11 bits) and rounds it once into the high half -- the same bits as the five instructions the
+// compiler makes of the C form (convert, convert back, subtract, convert, pack): 11 splits per scan, 34 VALU instructions fewer.
 __device__ __forceinline__ unsigned split_f16(float x) {
+#ifdef RTW_SPLIT_C_FORM
     const _Float16 p1 = (_Float16)x;
     const _Float16 p2 = (_Float16)(x - (float)p1);
     return (unsigned)__builtin_bit_cast(unsigned short, p1) | ((unsigned)__builtin_bit_cast(unsigned short, p2) << 16);
+#else
+    unsigned w;
+    __asm__("v_cvt_f16_f32_e32 %0, %1\n\tv_fma_mixhi_f16 %0, %1, 1.0, -%0 op_sel_hi:[0,0,1]" : "=&v"(w) : "v"(x));
+    return w;
+#endif
 }
 __device__ __forceinline__ float lane_get(float v, unsigned src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
