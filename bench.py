@@ -108,7 +108,7 @@ def parse_args(argv=None):
     ap.add_argument("--ray-pool", action="store_true", help="time the opt-in ray-pool kernel (RTW_FLAG_RAY_POOL) instead of the lane-loop kernel")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes that measure roofline.traffic / issue_busy in this run")
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per pixel (0 = library default rule)")
-    ap.add_argument("--numerics", choices=["reference", "contract", "reference_fma"], default="reference",
+    ap.add_argument("--numerics", choices=["reference", "contract", "reference_fma", "reference_fma2"], default="reference",
                     help="the deciding arithmetic of the ray-sphere test (include/rtw_hip.h RTW_FLAG_NUMERICS_*): reference = src/hit.jl:16-18 as the reference "
                          "evaluates it (the default of the library); the default run also times the other two as `numerics_legs`")
     ap.add_argument("--in-library-devices", type=int, default=0, metavar="N",
@@ -578,7 +578,7 @@ def main():
     numerics_legs = in_lib = None
     if extras and not (args.group_cull or args.scan_valu or args.ray_pool):
         numerics_legs = {}
-        for mode in ("reference", "contract", "reference_fma"):
+        for mode in ("reference", "contract", "reference_fma", "reference_fma2"):
             if mode == args.numerics:
                 continue
             stn = []

@@ -96,10 +96,13 @@ typedef struct {
  *                                    a callee, which @fastmath does not rewrite --, c = oc.oc - r^2, disc = half_b^2 - c, one rounding each
  *   RTW_FLAG_NUMERICS_REFERENCE_FMA  the same with the last step contracted, disc = fma(half_b, half_b, -c): what an FMA target gives if
  *                                    the square carries LLVM's `contract` flag
+ *   RTW_FLAG_NUMERICS_REFERENCE_FMA2 ... and c = fma(-r, r, oc.oc) as well: what LLVM emits for an FMA target when BOTH squares of lines 17-18 carry
+ *                                    fast-math flags (tools/llvm_fastmath_check/: with the flag-less llvm.powi of Julia's pow_fast neither site is fused)
  *   RTW_FLAG_NUMERICS_CONTRACT       ABI 2's arithmetic: half_b, r^2 - |oc|^2 and disc as three FMA chains
- * The two bits exclude each other.  tools/julia_kat.jl + tools/check_julia_kat.py decide between them on a Julia box. */
+ * The bits exclude each other.  tools/julia_kat.jl + tools/check_julia_kat.py decide between them on a Julia box. */
 #define RTW_FLAG_NUMERICS_CONTRACT 32
 #define RTW_FLAG_NUMERICS_REFERENCE_FMA 64
+#define RTW_FLAG_NUMERICS_REFERENCE_FMA2 128
 /* Measurement / test switches of the ENVIRONMENT (RTW_SCAN, RTW_POOL, RTW_JOB_PIXELS, RTW_ROWS_SHIFT, RTW_NO_HUGE,
  * RTW_DEBUG_REMOTE_SHARDS, RTW_DEBUG_NO_PEER, RTW_PHASE_PROFILE, RTW_DRAIN_PROFILE, RTW_DEBUG) are honoured only when the master switch
  * RTW_ENABLE_TEST_AIDS=1 is set too (read once per process).  Without it a stray variable changes nothing: a render's kernel choice, launch
@@ -203,7 +206,7 @@ int rtw_stats_devices(int32_t capacity, int32_t *count, int32_t *devices, double
  *       13 hit_world_mfma (pass 1 on the matrix pipe: the trace kernel's plain scan), scene staged in LDS;
  *          tmin of ray 0 serves the whole launch, tmax is +inf
  *       14 the same with block culling (RTW_FLAG_GROUP_CULL on the matrix pipe), cull layout staged in LDS
- *   bits 8-9 of `op`: the numerics mode of the ray-sphere test for ops 0, 8 - 11, 13, 14 (0 reference, 1 contract, 2 reference_fma)  */
+ *   bits 8-9 of `op`: the numerics mode of the ray-sphere test for ops 0, 8 - 11, 13, 14 (0 reference, 1 contract, 2 reference_fma, 3 reference_fma2)  */
 int rtw_unit_f32(int op, int count, const void *in, void *out, const rtw_scene_f32 *scene,
                  const rtw_camera_f32 *cam);
 int rtw_unit_f64(int op, int count, const void *in, void *out, const rtw_scene_f64 *scene,

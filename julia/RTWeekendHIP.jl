@@ -71,7 +71,7 @@ Drop-in for `RayTracingWeekend.render` (src/render.jl:8-44) on MI355X.  Keyword 
 `devices=:all` uses every visible GPU, `devices=[0, 1, 2]` the listed ones (the 8x8 tiles are dealt
 round-robin to the devices inside the library; the image is identical for any device list).
 `numerics` selects the deciding arithmetic of `hit(::Sphere)` (src/hit.jl:16-18): `:reference` (default) = the reference's own order -- StaticArrays' un-fused
-`dot`, one rounding per written operation --, `:reference_fma` = the same with `disc = fma(half_b, half_b, -c)`, `:contract` = three FMA chains
+`dot`, one rounding per written operation --, `:reference_fma` = the same with `disc = fma(half_b, half_b, -c)`, `:reference_fma2` = … and `c = fma(-r, r, oc⋅oc)`, `:contract` = three FMA chains
 (RTW_FLAG_NUMERICS_*; in Float32 the choice moves the image mean by 0.003 and the work by 4 %: `tools/julia_kat.jl` tells which one this Julia build emits).
 `group_cull=true` selects the opt-in culling scan (RTW_FLAG_GROUP_CULL), `scan_valu=true` the all-VALU form of either
 scan (RTW_FLAG_SCAN_VALU, for A/B measurements), `ray_pool=true` the ray-pool kernel (RTW_FLAG_RAY_POOL): same image bit for bit in every mode.
@@ -79,8 +79,8 @@ scan (RTW_FLAG_SCAN_VALU, for A/B measurements), `ray_pool=true` the ray-pool ke
 """
 function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=1;
                 depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, numerics=:reference, group_cull=false, scan_valu=false, ray_pool=false, rccl_reduce=false) where T <: Union{Float32,Float64}
-    numerics in (:reference, :contract, :reference_fma) || throw(ArgumentError("numerics must be :reference, :contract or :reference_fma"))
-    nflags = numerics === :contract ? 32 : numerics === :reference_fma ? 64 : 0         # RTW_FLAG_NUMERICS_CONTRACT / _REFERENCE_FMA
+    numerics in (:reference, :contract, :reference_fma, :reference_fma2) || throw(ArgumentError("numerics must be :reference, :contract, :reference_fma or :reference_fma2"))
+    nflags = numerics === :contract ? 32 : numerics === :reference_fma ? 64 : numerics === :reference_fma2 ? 128 : 0         # RTW_FLAG_NUMERICS_CONTRACT / _REFERENCE_FMA / _REFERENCE_FMA2
     image_height = image_width ÷ (16//9)                       # src/render.jl:11-12
     n = length(scene)
     cx = Vector{T}(undef, n); cy = similar(cx); cz = similar(cx); r = similar(cx)

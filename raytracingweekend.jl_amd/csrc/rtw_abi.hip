@@ -117,8 +117,9 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
-    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_RAY_POOL | RTW_FLAG_RCCL_REDUCE | RTW_FLAG_NUMERICS_CONTRACT | RTW_FLAG_NUMERICS_REFERENCE_FMA)) return fail(-2, "unknown flags 0x%x", p->flags);
-    if ((p->flags & RTW_FLAG_NUMERICS_CONTRACT) && (p->flags & RTW_FLAG_NUMERICS_REFERENCE_FMA)) return fail(-2, "RTW_FLAG_NUMERICS_CONTRACT and RTW_FLAG_NUMERICS_REFERENCE_FMA exclude each other");
+    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_RAY_POOL | RTW_FLAG_RCCL_REDUCE | RTW_FLAG_NUMERICS_CONTRACT | RTW_FLAG_NUMERICS_REFERENCE_FMA | RTW_FLAG_NUMERICS_REFERENCE_FMA2)) return fail(-2, "unknown flags 0x%x", p->flags);
+    { const int nm = p->flags & (RTW_FLAG_NUMERICS_CONTRACT | RTW_FLAG_NUMERICS_REFERENCE_FMA | RTW_FLAG_NUMERICS_REFERENCE_FMA2);
+      if (nm & (nm - 1)) return fail(-2, "the RTW_FLAG_NUMERICS_* bits exclude each other (flags 0x%x)", p->flags); }
     // default rule: about 4 samples per chunk, between 16 and 256 chunks (never more than spp):
     // enough items for load balance, few enough stream set-ups (1 sample per chunk costs 7 % at Float64)
     int nch = p->n_chunks > 0 ? p->n_chunks : std::min(p->spp, std::max(16, std::min(256, p->spp / 4)));

@@ -154,12 +154,15 @@ template <typename T> __device__ __forceinline__ void random_vec2_in_disk(Rng &r
 //                            @fastmath does not rewrite: (x1 y1 + x2 y2) + x3 y3, no FMA --, then  c = oc.oc - r^2  and
 //                            disc = half_b^2 - c  with one rounding each
 //   NUM_REFERENCE_FMA        the same with the last step contracted: disc = fma(half_b, half_b, -c)
+//   NUM_REFERENCE_FMA2       ... and c = fma(-r, r, oc.oc) as well: what LLVM makes of src/hit.jl:17-18 on an FMA target when BOTH squares carry
+//                            fast-math flags (tools/llvm_fastmath_check: with the flag-less llvm.powi that Julia's pow_fast emits, neither is fused)
 //   NUM_CONTRACT             rounds 1 - 4: half_b, r^2 - |oc|^2 and disc as three FMA chains
 // (this file is compiled with -ffp-contract=off: the un-fused forms stay un-fused).
-enum { NUM_REFERENCE = 0, NUM_CONTRACT = 1, NUM_REFERENCE_FMA = 2 };
+enum { NUM_REFERENCE = 0, NUM_CONTRACT = 1, NUM_REFERENCE_FMA = 2, NUM_REFERENCE_FMA2 = 3 };
 template <int N> struct NumTag { static constexpr int value = N; };
+// `r`: the sphere's radius itself -- read only by NUM_REFERENCE_FMA2 (c = fma(-r, r, oc.oc): the un-rounded square)
 template <typename T, int NUM>
-__device__ __forceinline__ void sphere_disc_n(T cx, T cy, T cz, T r2, V3<T> o, V3<T> d, T &half_b, T &disc) {
+__device__ __forceinline__ void sphere_disc_n(T cx, T cy, T cz, T r2, [[maybe_unused]] T r, V3<T> o, V3<T> d, T &half_b, T &disc) {
     const T ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
     if constexpr (NUM == NUM_CONTRACT) {
         half_b = t_fma(ocz, d.z, t_fma(ocy, d.y, ocx * d.x));
@@ -167,17 +170,19 @@ __device__ __forceinline__ void sphere_disc_n(T cx, T cy, T cz, T r2, V3<T> o, V
         disc = t_fma(half_b, half_b, nc);
     } else {
         half_b = (ocx * d.x + ocy * d.y) + ocz * d.z;                       // src/hit.jl:16
-        const T c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;             // :17
+        const T ococ = (ocx * ocx + ocy * ocy) + ocz * ocz;
+        const T c = NUM == NUM_REFERENCE_FMA2 ? t_fma(-r, r, ococ) : ococ - r2;   // :17
         if constexpr (NUM == NUM_REFERENCE) disc = half_b * half_b - c;     // :18 (a == 1)
         else disc = t_fma(half_b, half_b, -c);
     }
 }
 // `num` is wave-uniform (a kernel argument): real scalar branches
 template <typename T>
-__device__ __forceinline__ void sphere_disc(int num, T cx, T cy, T cz, T r2, V3<T> o, V3<T> d, T &half_b, T &disc) {
-    if (num == NUM_REFERENCE) sphere_disc_n<T, NUM_REFERENCE>(cx, cy, cz, r2, o, d, half_b, disc);
-    else if (num == NUM_CONTRACT) sphere_disc_n<T, NUM_CONTRACT>(cx, cy, cz, r2, o, d, half_b, disc);
-    else sphere_disc_n<T, NUM_REFERENCE_FMA>(cx, cy, cz, r2, o, d, half_b, disc);
+__device__ __forceinline__ void sphere_disc(int num, T cx, T cy, T cz, T r2, T r, V3<T> o, V3<T> d, T &half_b, T &disc) {
+    if (num == NUM_REFERENCE) sphere_disc_n<T, NUM_REFERENCE>(cx, cy, cz, r2, r, o, d, half_b, disc);
+    else if (num == NUM_CONTRACT) sphere_disc_n<T, NUM_CONTRACT>(cx, cy, cz, r2, r, o, d, half_b, disc);
+    else if (num == NUM_REFERENCE_FMA) sphere_disc_n<T, NUM_REFERENCE_FMA>(cx, cy, cz, r2, r, o, d, half_b, disc);
+    else sphere_disc_n<T, NUM_REFERENCE_FMA2>(cx, cy, cz, r2, r, o, d, half_b, disc);
 }
 // src/hit.jl:19-29: root selection against [tmin, closest]; returns true and the root on a hit
 template <typename T>
@@ -458,13 +463,14 @@ struct NoClock { __device__ __forceinline__ void lap(int) {} __device__ __forcei
 //           global array for scenes too large for LDS); the loop is software-pipelined: entry
 //           c+1's index and sphere are fetched while entry c is tested.
 template <typename T, int STRIDE, int NUM, typename SRC>
-__device__ __forceinline__ void resolve_candidates_n(SRC src, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
+__device__ __forceinline__ void resolve_candidates_n(SRC src, const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
                                                      const unsigned short *list, int cnt) {
     using V4 = typename Vec4<T>::type;
     auto test = [&](int c, int i, const V4 &s) {
         if (c < cnt) {
-            T hb, disc, root;
-            sphere_disc_n<T, NUM>(s.x, s.y, s.z, s.w, o, d, hb, disc);
+            T hb, disc, root, r = T(0);
+            if constexpr (NUM == NUM_REFERENCE_FMA2) r = rad[i].x;           // (mat0[i].x: the radius itself)
+            sphere_disc_n<T, NUM>(s.x, s.y, s.z, s.w, r, o, d, hb, disc);
             if (sphere_root<T>(hb, disc, tmin, closest, root)) { closest = root; idx = i; }
         }
     };
@@ -482,11 +488,12 @@ __device__ __forceinline__ void resolve_candidates_n(SRC src, V3<T> o, V3<T> d, 
 }
 // (the numerics mode is wave-uniform: one scalar branch per call, not per candidate)
 template <typename T, int STRIDE, typename SRC>
-__device__ __forceinline__ void resolve_candidates(int num, SRC src, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
+__device__ __forceinline__ void resolve_candidates(int num, SRC src, const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
                                                    const unsigned short *list, int cnt) {
-    if (num == NUM_REFERENCE) resolve_candidates_n<T, STRIDE, NUM_REFERENCE>(src, o, d, tmin, closest, idx, list, cnt);
-    else if (num == NUM_CONTRACT) resolve_candidates_n<T, STRIDE, NUM_CONTRACT>(src, o, d, tmin, closest, idx, list, cnt);
-    else resolve_candidates_n<T, STRIDE, NUM_REFERENCE_FMA>(src, o, d, tmin, closest, idx, list, cnt);
+    if (num == NUM_REFERENCE) resolve_candidates_n<T, STRIDE, NUM_REFERENCE>(src, rad, o, d, tmin, closest, idx, list, cnt);
+    else if (num == NUM_CONTRACT) resolve_candidates_n<T, STRIDE, NUM_CONTRACT>(src, rad, o, d, tmin, closest, idx, list, cnt);
+    else if (num == NUM_REFERENCE_FMA) resolve_candidates_n<T, STRIDE, NUM_REFERENCE_FMA>(src, rad, o, d, tmin, closest, idx, list, cnt);
+    else resolve_candidates_n<T, STRIDE, NUM_REFERENCE_FMA2>(src, rad, o, d, tmin, closest, idx, list, cnt);
 }
 
 template <typename T, int STRIDE, typename SRC, typename CLK = NoClock>
@@ -542,7 +549,18 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
             mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(W), 31);
         } else {
             T hb, disc;
-            sphere_disc_n<T, decltype(tag)::value>(sp.v[0], sp.v[1], sp.v[2], sp.v[3], o, d, hb, disc);
+            if constexpr (decltype(tag)::value == NUM_REFERENCE_FMA2) {
+                // The scalar stream carries r^2, not r: pass 1 evaluates the reference_fma form and adds a margin that covers what the
+                // un-rounded square can change -- the two values of c differ by <= u r^2 (the rounding of r r) + 2 u (oc.oc + r^2) (their
+                // own roundings), the two final fmas by <= 2 u (half_b^2 + oc.oc + r^2): < 8 u (oc.oc + r^2) = 2^-21 (oc.oc + r^2) in all.
+                // A superset is all pass 1 owes; pass 2 decides with the radius itself.
+                const T ocx = o.x - sp.v[0], ocy = o.y - sp.v[1], ocz = o.z - sp.v[2];
+                hb = (ocx * d.x + ocy * d.y) + ocz * d.z;
+                const T ococ = (ocx * ocx + ocy * ocy) + ocz * ocz;
+                disc = t_fma(ococ + sp.v[3], T(4.76837158203125e-07), t_fma(hb, hb, -(ococ - sp.v[3])));
+            } else {
+                sphere_disc_n<T, decltype(tag)::value>(sp.v[0], sp.v[1], sp.v[2], sp.v[3], T(0), o, d, hb, disc);
+            }
             mask = __builtin_amdgcn_alignbit(mask, sign_word(disc), 31);
         }
     };
@@ -598,7 +616,7 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
             while (__any(m != 0u)) {
                 if (__any(cnt >= RTW_LIST_CAP)) {     // some lane's list is full: resolve all lists now
                     clk.lap(4);
-                    resolve_candidates<T, STRIDE>(w.numerics, src, o, d, tmin, closest, idx, list, cnt);
+                    resolve_candidates<T, STRIDE>(w.numerics, src, w.mat0, o, d, tmin, closest, idx, list, cnt);
                     cnt = 0;
                     clk.lap(5);
                 }
@@ -611,11 +629,12 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
     if constexpr (F64) scan(NumTag<NUM_REFERENCE>{});        // (the binary32 filter does not depend on the mode)
     else if (w.numerics == NUM_REFERENCE) scan(NumTag<NUM_REFERENCE>{});
     else if (w.numerics == NUM_CONTRACT) scan(NumTag<NUM_CONTRACT>{});
-    else scan(NumTag<NUM_REFERENCE_FMA>{});
-    resolve_candidates<T, STRIDE>(w.numerics, src, o, d, tmin, closest, idx, list, cnt);
+    else if (w.numerics == NUM_REFERENCE_FMA) scan(NumTag<NUM_REFERENCE_FMA>{});
+    else scan(NumTag<NUM_REFERENCE_FMA2>{});
+    resolve_candidates<T, STRIDE>(w.numerics, src, w.mat0, o, d, tmin, closest, idx, list, cnt);
 #ifdef RTW_DUP_RESOLVE   // instruction-count probe: the final resolve twice (idempotent: same winner)
     { T c2 = tmax; int i2 = -1; __asm__ volatile("" : "+v"(c2), "+v"(i2));
-      resolve_candidates<T, STRIDE>(w.numerics, src, o, d, tmin, c2, i2, list, cnt);
+      resolve_candidates<T, STRIDE>(w.numerics, src, w.mat0, o, d, tmin, c2, i2, list, cnt);
       __asm__ volatile("" :: "v"(c2), "v"(i2)); }
 #endif
     clk.lap(5);
@@ -697,6 +716,7 @@ struct MfmaCull {
     const float *box;
     int blocks;
     float cs[3], rs;      // bounding sphere of the small class (the margin grows with the distance to it)
+    const void *mat0;     // the cold rows in this (device) order: mat0[i].x = the radius (NUM_REFERENCE_FMA2)
     float glo[3], ghi[3]; // the box of the whole small class (the union of its blocks' boxes): a ray is clipped against it ONCE per scan
     int n_huge, huge[2];  // huge spheres (device order), tested in-lane like DevScene::huge
 };
@@ -757,8 +777,8 @@ __device__ unsigned g_cand_hist[8192];
 #endif
 // Walk n entries of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
 struct NoOrig {};
-template <typename T, typename SRC, typename ORIG = NoOrig>
-__device__ __forceinline__ void resolve_pairs(int num, SRC src, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
+template <typename T, bool WITH_R, typename SRC, typename ORIG = NoOrig>
+__device__ __forceinline__ void resolve_pairs_impl(int num, SRC src, const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
     constexpr bool CULLED = !__is_same(ORIG, NoOrig);      // device order != the caller's order: ties go by orig[], the key carries both
     constexpr unsigned G = RTW_SCAN_GROUP;
     using V4 = typename Vec4<T>::type;
@@ -783,7 +803,8 @@ __device__ __forceinline__ void resolve_pairs(int num, SRC src, V3<T> o, V3<T> d
             const unsigned sph = sph0 + m;
             const V4 s = sg[m];
             T hb, disc, root = 0;
-            sphere_disc<T>(num, s.x, s.y, s.z, s.w, po, pd, hb, disc);
+            if constexpr (WITH_R) sphere_disc_n<T, NUM_REFERENCE_FMA2>(s.x, s.y, s.z, s.w, rad[sph].x, po, pd, hb, disc);   // (mat0: the radius itself; the LDS copy holds r^2)
+            else sphere_disc<T>(num, s.x, s.y, s.z, s.w, T(0), po, pd, hb, disc);
 #ifdef RTW_CAND_HIST
             if (valid && sph < 4096u) atomicAdd(&g_cand_hist[2u * sph + (disc < T(0) ? 0u : 1u)], 1u);
 #endif
@@ -813,6 +834,13 @@ __device__ __forceinline__ void resolve_pairs(int num, SRC src, V3<T> o, V3<T> d
     __builtin_amdgcn_wave_barrier();
 }
 
+// (NUM_REFERENCE_FMA2 reads the radius from mat0: its own copy of the loop, so that the other modes keep their registers)
+template <typename T, typename SRC, typename ORIG = NoOrig>
+__device__ __forceinline__ void resolve_pairs(int num, SRC src, const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
+    if (num == NUM_REFERENCE_FMA2) resolve_pairs_impl<T, true>(num, src, rad, o, d, tmin, ws, n, lane, orig);
+    else resolve_pairs_impl<T, false>(num, src, rad, o, d, tmin, ws, n, lane, orig);
+}
+
 // Closest hit for the rays of a whole wave (every lane calls it, convergently; has_ray = this lane has a ray).
 // With `mc` (group cull, RTW_FLAG_GROUP_CULL): the spheres come in the cull layout's device order (src, orig), and a block of
 // 32 is skipped when NO ray of the wave can touch its box -- the slab test of hit_world_cull (same conservative margin, in
@@ -822,6 +850,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
                                               const WaveScratch &ws, unsigned lane, CLK &&clk = NoClock(),
                                               const MfmaCull *mc = nullptr, ORIG orig = ORIG()) {
     constexpr bool CULLED = !__is_same(ORIG, NoOrig);
+    const typename Vec4<T>::type *rad = CULLED ? (const typename Vec4<T>::type *)mc->mat0 : w.mat0;      // radii (mat0[i].x), in the order of `src`: NUM_REFERENCE_FMA2 only
     // ---- ray features (binary32) ----
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     const float s2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -915,7 +944,9 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             const int si = CULLED ? (hgi == 0 ? mc->huge[0] : mc->huge[1]) : (hgi == 0 ? w.huge[0] : w.huge[1]);      // (no dynamic indexing of a by-value struct: that would live in scratch)
             const V4 sg = src[si];
             T hb_, disc_, root_ = 0;
-            sphere_disc<T>(w.numerics, sg.x, sg.y, sg.z, sg.w, o, d, hb_, disc_);
+            T rr_ = T(0);
+            if (w.numerics == NUM_REFERENCE_FMA2) rr_ = rad[si].x;
+            sphere_disc<T>(w.numerics, sg.x, sg.y, sg.z, sg.w, rr_, o, d, hb_, disc_);
             if (has_ray && sphere_root<T>(hb_, disc_, tmin, (T)__builtin_huge_val(), root_)) {
                 unsigned tie = (unsigned)si;                       // larger = later in the caller's list (resolve_pairs)
                 if constexpr (CULLED) tie = ((unsigned)orig[si] << 16) | (unsigned)si;
@@ -1053,7 +1084,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             for (int r = 0; r < 16; ++r) {
                 const unsigned long long cm = __ballot(!(Wv[r] < 0.0f));
                 if (cm) {
-                    if (total + 64u > ws.cap) { resolve_pairs<T>(w.numerics, src, o, d, tmin, ws, total, lane, orig); total = 0; }
+                    if (total + 64u > ws.cap) { resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig); total = 0; }
                     if (!(Wv[r] < 0.0f))
                         ws.pairs[__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, total))] = lane_const + (unsigned)blk_ * 32u + half16 + (unsigned)r;
                     total += (unsigned)__popcll(cm);
@@ -1158,7 +1189,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             if (!act) break;
             if (total + 64u > ws.cap) {
                 clk.lap(4);
-                resolve_pairs<T>(w.numerics, src, o, d, tmin, ws, total, lane, orig);
+                resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig);
                 total = 0;
                 clk.lap(5);
             }
@@ -1173,9 +1204,9 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         clk.lap(4);
     }
     if (use_prio) __builtin_amdgcn_s_setprio(sizeof(T) == 4 ? 1 : 0);
-    resolve_pairs<T>(w.numerics, src, o, d, tmin, ws, total, lane, orig);
+    resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig);
 #ifdef RTW_DUP_RESOLVE_PAIRS   // instruction/time probe: the final resolve twice (idempotent: min / max of the same keys)
-    resolve_pairs<T>(w.numerics, src, o, d, tmin, ws, total, lane, orig);
+    resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig);
 #endif
     clk.lap(5);
     int idx;
@@ -1245,7 +1276,7 @@ template <typename T> struct CullScene {
     int numerics;                          // NUM_* (see DevScene::numerics)
 };
 template <typename T> __host__ __device__ inline MfmaCull mfma_cull_of(const CullScene<T> &c) {
-    return MfmaCull{c.mf_ops, c.mf_box, c.mf_blocks, {(float)c.cs[0], (float)c.cs[1], (float)c.cs[2]}, (float)c.rs * 1.000001f + 1e-30f,
+    return MfmaCull{c.mf_ops, c.mf_box, c.mf_blocks, {(float)c.cs[0], (float)c.cs[1], (float)c.cs[2]}, (float)c.rs * 1.000001f + 1e-30f, (const void *)c.mat0,
                     {c.mf_glo[0], c.mf_glo[1], c.mf_glo[2]}, {c.mf_ghi[0], c.mf_ghi[1], c.mf_ghi[2]}, c.n_huge, {c.huge[0], c.huge[1]}};
 }
 template <typename T> __host__ __device__ inline int cull_exact_count(const CullScene<T> &c) { return c.n_groups_pad * RTW_CULL_GS + ((c.n_big + 31) / 32) * 32; }   // (allocated in whole blocks of 32: dead slots behind the BIG class)
@@ -1256,7 +1287,7 @@ __device__ __forceinline__ double t_min(double a, double b) { return __builtin_f
 __device__ __forceinline__ double t_max(double a, double b) { return __builtin_fmax(a, b); }
 
 template <typename T, int STRIDE, typename SRC, typename ORIG>
-__device__ __forceinline__ void resolve_candidates_anyorder(int num, SRC src, ORIG orig, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
+__device__ __forceinline__ void resolve_candidates_anyorder(int num, SRC src, const typename Vec4<T>::type *rad, ORIG orig, V3<T> o, V3<T> d, T tmin, T &closest, int &idx,
                                                             const unsigned short *list, int cnt) {
     using V4 = typename Vec4<T>::type;
     int i_next = cnt > 0 ? (int)list[0] : 0;
@@ -1268,7 +1299,9 @@ __device__ __forceinline__ void resolve_candidates_anyorder(int num, SRC src, OR
         s_next = src[i_next];
         if (c < cnt) {
             T hb, disc, root;
-            sphere_disc<T>(num, s.x, s.y, s.z, s.w, o, d, hb, disc);
+            T rr = T(0);
+            if (num == NUM_REFERENCE_FMA2) rr = rad[i].x;
+            sphere_disc<T>(num, s.x, s.y, s.z, s.w, rr, o, d, hb, disc);
             if (sphere_root<T>(hb, disc, tmin, closest, root)) {       // root in [tmin, closest]
                 bool take = true;
                 if (root == closest && idx >= 0) take = orig[i] > orig[idx];
@@ -1290,7 +1323,7 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
     int idx = -1, cnt = 0;
     auto push = [&](int i) {                       // lane-local: may run in divergent code
         if (cnt >= RTW_LIST_CAP) {
-            resolve_candidates_anyorder<T, STRIDE>(w.numerics, src, orig, o, d, tmin, closest, idx, list, cnt);
+            resolve_candidates_anyorder<T, STRIDE>(w.numerics, src, w.mat0, orig, o, d, tmin, closest, idx, list, cnt);
             cnt = 0;
         }
         list[cnt * STRIDE] = (unsigned short)i;
@@ -1300,7 +1333,9 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
     // spheres entirely behind the ray are not even listed.
     auto member = [&](const V4 &sp, int i) {
         T hb, disc;
-        sphere_disc<T>(w.numerics, sp.x, sp.y, sp.z, sp.w, o, d, hb, disc);
+        T rr = T(0);
+        if (w.numerics == NUM_REFERENCE_FMA2) rr = w.mat0[i].x;
+        sphere_disc<T>(w.numerics, sp.x, sp.y, sp.z, sp.w, rr, o, d, hb, disc);
         if (!(disc < T(0))) { if (!(hb > T(0)) || disc > hb * hb) push(i); }
     };
 
@@ -1388,7 +1423,7 @@ __device__ __forceinline__ int hit_world_cull(const CullScene<T> &w, SRC src, OR
         }
         clk.lap(4);
     }
-    resolve_candidates_anyorder<T, STRIDE>(w.numerics, src, orig, o, d, tmin, closest, idx, list, cnt);
+    resolve_candidates_anyorder<T, STRIDE>(w.numerics, src, w.mat0, orig, o, d, tmin, closest, idx, list, cnt);
     clk.lap(5);
     t_hit = closest;
     return idx;

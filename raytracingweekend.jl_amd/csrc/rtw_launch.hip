@@ -51,7 +51,8 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     using V4 = typename rtw::Vec4<T>::type;
     rtw::DevScene<T> S = dev_scene_of<T>(scene);
     // the deciding arithmetic of the ray-sphere test (include/rtw_hip.h RTW_FLAG_NUMERICS_*): a property of the render, not of the upload
-    S.numerics = (p->flags & RTW_FLAG_NUMERICS_CONTRACT) ? rtw::NUM_CONTRACT : (p->flags & RTW_FLAG_NUMERICS_REFERENCE_FMA) ? rtw::NUM_REFERENCE_FMA : rtw::NUM_REFERENCE;
+    S.numerics = (p->flags & RTW_FLAG_NUMERICS_CONTRACT) ? rtw::NUM_CONTRACT : (p->flags & RTW_FLAG_NUMERICS_REFERENCE_FMA) ? rtw::NUM_REFERENCE_FMA :
+                 (p->flags & RTW_FLAG_NUMERICS_REFERENCE_FMA2) ? rtw::NUM_REFERENCE_FMA2 : rtw::NUM_REFERENCE;
 
     // persistent grid: enough 256-thread blocks to fill every CU at the kernel's occupancy
     static const bool phase_profile = aid_env("RTW_PHASE_PROFILE") != nullptr;   // debugging aid, not for timed runs

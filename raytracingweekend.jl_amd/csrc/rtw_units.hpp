@@ -79,7 +79,7 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
             V3<T> c = ld3<T>(x), o = ld3<T>(x + 4), d = ld3<T>(x + 7);
             T r = (T)x[3], tmin = (T)x[10], tmax = (T)x[11];
             T hb, disc, root;
-            sphere_disc<T>(scene.numerics, c.x, c.y, c.z, r * r, o, d, hb, disc);
+            sphere_disc<T>(scene.numerics, c.x, c.y, c.z, r * r, r, o, d, hb, disc);
             for (int k = 0; k < 9; ++k) y[k] = 0.0;
             if (sphere_root<T>(hb, disc, tmin, tmax, root)) {
                 HitRec<T> rec;

@@ -32,7 +32,7 @@ def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chun
     ``devices``: ``"all"`` or a list of HIP ordinals -- the 8x8 tiles are dealt to those devices
     inside the library (``rtw_params.n_devices/device_ids``); the image is the same for any list.
     ``numerics``: the deciding arithmetic of ``hit(::Sphere)`` (src/hit.jl:16-18): ``"reference"`` (default: StaticArrays' un-fused
-    dot, one rounding per written operation), ``"reference_fma"`` (the last step contracted) or ``"contract"`` (the three FMA
+    dot, one rounding per written operation), ``"reference_fma"`` (the last step contracted), ``"reference_fma2"`` (both squares contracted) or ``"contract"`` (the three FMA
     chains of ABI 2); include/rtw_hip.h RTW_FLAG_NUMERICS_*.
     ``rccl_reduce=True`` (with ``devices``): the shards are put together by ONE ncclReduce of zero-padded frames inside the
     library (RTW_FLAG_RCCL_REDUCE) instead of peer copies of compact shards; ``last_stats()["gather_path"]`` says which path ran."""

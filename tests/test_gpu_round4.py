@@ -355,7 +355,7 @@ def test_bench_line_contract_and_live_counters():
     # round 5: the numerics mode and its counter in the line, the other modes as legs with their own (different) frames, the in-library device list
     assert d["numerics"] == "reference" and d["config"]["numerics"].startswith("reference") and 3.0 < d["segments_per_sample"] < 5.0
     nl = d["numerics_legs"]
-    assert set(nl) == {"contract", "reference_fma"} and nl["contract"]["frame_sha256"] != d["frame_sha256"]
+    assert set(nl) == {"contract", "reference_fma", "reference_fma2"} and nl["contract"]["frame_sha256"] != d["frame_sha256"]
     assert nl["contract"]["segments_per_sample"] < nl["reference_fma"]["segments_per_sample"] < d["segments_per_sample"]
     il = d["in_library_devices"]
     assert il["n_devices"] >= 2 and il["peer"]["frame_sha256_equal"] is True and il["rccl_reduce"]["frame_sha256_equal"] is True

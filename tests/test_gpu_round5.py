@@ -25,13 +25,14 @@ def test_numerics_flags_select_the_oracles_modes(oracle):
     from rtw_amd import _capi
     name = "cfg2_random_320x180_64spp_d16_f32"
     seen = {}
-    for mode, bits in (("reference", 0), ("contract", _capi.FLAG_NUMERICS_CONTRACT), ("reference_fma", _capi.FLAG_NUMERICS_REFERENCE_FMA)):
+    for mode, bits in (("reference", 0), ("contract", _capi.FLAG_NUMERICS_CONTRACT), ("reference_fma", _capi.FLAG_NUMERICS_REFERENCE_FMA),
+                       ("reference_fma2", _capi.FLAG_NUMERICS_REFERENCE_FMA2)):
         g = load_golden(name, numerics=mode)
         for flags in (0, _capi.FLAG_SCAN_VALU, _capi.FLAG_GROUP_CULL, _capi.FLAG_GROUP_CULL | _capi.FLAG_SCAN_VALU, _capi.FLAG_RAY_POOL):
             img, st = gpu_render(g, flags=flags | bits)
             assert np.array_equal(img, g["image"]) and st.segments == g["segments"], (mode, flags)
         seen[mode] = (g["image"], g["segments"])
-    assert seen["reference"][1] > seen["reference_fma"][1] > seen["contract"][1]               # tmin re-hits of the ground sphere
+    assert seen["reference"][1] > seen["reference_fma"][1] > seen["contract"][1] and seen["reference_fma2"][1] > seen["contract"][1]               # tmin re-hits of the ground sphere
     assert not np.array_equal(seen["reference"][0], seen["contract"][0])
     with pytest.raises(_capi.RtwError, match="exclude each other"):
         gpu_render(load_golden(name), flags=_capi.FLAG_NUMERICS_CONTRACT | _capi.FLAG_NUMERICS_REFERENCE_FMA)

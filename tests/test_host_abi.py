@@ -44,11 +44,12 @@ def test_flag_constants_match_header(rtw):
     """the Python mirror, the Julia shim and include/rtw_hip.h agree on rtw_params.flags"""
     from rtw_amd import _capi
     header = open(os.path.join(ROOT, "include", "rtw_hip.h")).read()
-    flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+RTW_FLAG_([A-Z_]+)\s+(\d+)", header)}
+    flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+RTW_FLAG_([A-Z0-9_]+)\s+(\d+)", header)}
     assert flags == {"GROUP_CULL": _capi.FLAG_GROUP_CULL, "COMPACT_TILES": _capi.FLAG_COMPACT_TILES, "SCAN_VALU": _capi.FLAG_SCAN_VALU,
                      "RAY_POOL": _capi.FLAG_RAY_POOL, "RCCL_REDUCE": _capi.FLAG_RCCL_REDUCE,
-                     "NUMERICS_CONTRACT": _capi.FLAG_NUMERICS_CONTRACT, "NUMERICS_REFERENCE_FMA": _capi.FLAG_NUMERICS_REFERENCE_FMA}
-    assert sorted(flags.values()) == [1, 2, 4, 8, 16, 32, 64]
+                     "NUMERICS_CONTRACT": _capi.FLAG_NUMERICS_CONTRACT, "NUMERICS_REFERENCE_FMA": _capi.FLAG_NUMERICS_REFERENCE_FMA,
+                     "NUMERICS_REFERENCE_FMA2": _capi.FLAG_NUMERICS_REFERENCE_FMA2}
+    assert sorted(flags.values()) == [1, 2, 4, 8, 16, 32, 64, 128]
     jl = open(os.path.join(ROOT, "julia", "RTWeekendHIP.jl")).read()
     assert "(group_cull ? 1 : 0) | (scan_valu ? 4 : 0) | (ray_pool ? 8 : 0) | (rccl_reduce ? 16 : 0)" in jl
 
@@ -180,7 +181,7 @@ def test_julia_shim_struct_layouts_match_the_c_abi():
         assert [(o, s) for _, o, s in lay] == [(o, s) for _, o, s in cf], (jl, lay, cf)
         assert [n for n, _, _ in lay] == [n for n, _, _ in cf], jl
     assert "v == 3 ||" in src and _capi.ABI_VERSION == 3
-    assert "numerics === :contract ? 32 : numerics === :reference_fma ? 64 : 0" in src            # the flag bits of include/rtw_hip.h
+    assert "numerics === :contract ? 32 : numerics === :reference_fma ? 64 : numerics === :reference_fma2 ? 128 : 0" in src            # the flag bits of include/rtw_hip.h
 
 
 def test_check_julia_kat_detects_a_wrong_assumption(tmp_path):
@@ -216,6 +217,20 @@ def test_check_julia_kat_names_the_numerics_mode(tmp_path, mode):
     line = next(x for x in r.stdout.splitlines() if x.startswith("numerics of hit(::Sphere{Float32})"))
     counts = {m: tuple(int(v) for v in c.split("/")) for m, c in (part.strip().rsplit(" ", 1) for part in line.split("reproduced:", 1)[1].split(","))}
     assert counts[mode][0] == counts[mode][1] and all(c[0] <= c[1] - 20 for m, c in counts.items() if m != mode), counts     # every other mode misses >= 20 rays
+
+
+def test_llvm_contraction_experiment():
+    """tools/llvm_fastmath_check: the x86 back end of the LLVM in this image, fed a reconstruction of the IR Julia emits for src/hit.jl:13-18,
+    fuses NOTHING when the squares are the flag-less llvm.powi of pow_fast (numerics mode `reference`, the default) and BOTH fsub-of-a-square
+    sites when the squares are `fmul fast` (mode `reference_fma2`) -- the evidence behind the default and the mode list."""
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm clang in this image")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "llvm_fastmath_check", "run.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "disc_julia: fused multiply-adds: 0" in r.stdout and "disc_fastsq: fused multiply-adds: 2" in r.stdout, r.stdout
+    assert "vfnmadd231ss" in r.stdout and "vfmsub231ss" in r.stdout
 
 
 def test_c_host_example_compiles_and_links(tmp_path):

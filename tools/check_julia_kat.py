@@ -248,7 +248,7 @@ def check(path):
             mode = f32[0]
             print(f"  -> this Julia evaluates src/hit.jl:16-18 as the oracle's `{mode}` mode" + (" (the library's default)" if mode == "reference" else
                   f": make it the default (include/rtw_hip.h RTW_FLAG_NUMERICS_*; `numerics` of render()), or pass numerics={mode!r}"
-                  + (" -- the device does not implement reference_fma2 yet: sphere_disc needs r next to r^2" if mode == "reference_fma2" else "")))
+                 ))
         elif not f32:
             print("  -> NO numerics mode of the oracle reproduces every record: inspect julia_hit_sphere_Float32.ll (fmuladd? contract flags? a reassociated dot?)")
         else:

@@ -11,14 +11,14 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 import numpy as np
 
-NUMERICS = ("reference", "contract", "reference_fma")      # the numerics mode of a round follows its seed: all three are soaked
+NUMERICS = ("reference", "contract", "reference_fma", "reference_fma2")      # the numerics mode of a round follows its seed: all four are soaked
 
 
 def _set_numerics(seed):
     """both sides -- the oracle and the product's Python mirror -- to the mode of this seed; returns (mode, restore())"""
     import rtw_oracle as O
     from rtw_amd import _capi
-    mode = NUMERICS[(seed // 2) % 3]
+    mode = NUMERICS[(seed // 2) % 4]
     prev = (O.set_numerics(mode), _capi.set_default_numerics(mode))
     return mode, (lambda: (O.set_numerics(prev[0]), _capi.set_default_numerics(prev[1])))
 
