@@ -589,9 +589,20 @@ def main():
                                    "frame_sha256": wl.frame_sha256() if rank == 0 else None,
                                    "note": "a DIFFERENT image by design: another evaluation order of src/hit.jl:16-18 (DESIGN.md section 4)"}
     if extras and world == 1:
+        # the in-library device list in a CHILD process (`bench.py --in-library-devices N`): on a multi-GPU box this is the first time the
+        # peer copies / the N-rank RCCL reduce run at all -- whatever happens there (an error, a hang) must not cost the headline line
         have = torch.cuda.device_count()
-        in_lib = in_library_leg(c, wl, have if have > 1 else 2, args.numerics, steps=max(1, min(args.steps, 2)))
-        in_lib.pop("sha_of")
+        cmd = [sys.executable, os.path.abspath(__file__), "--in-library-devices", str(have if have > 1 else 2), "--steps", str(max(1, min(args.steps, 2))),
+               "--dtype", args.dtype, "--width", str(W), "--spp", str(spp), "--depth", str(depth), "--numerics", args.numerics, "--chunks", str(args.chunks)]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            in_lib = json.loads(lines[-1])["in_library_devices"] if (r.returncode == 0 and lines) else {"error": f"exit code {r.returncode}: {r.stderr[-400:]}"}
+        except subprocess.TimeoutExpired:
+            in_lib = {"error": "timed out after 240 s"}
+        except Exception as e:
+            in_lib = {"error": str(e)[:300]}
         for k in ("peer", "rccl_reduce"):
             if "frame_sha256" in in_lib.get(k, {}):
                 in_lib[k]["frame_sha256_equal"] = in_lib[k]["frame_sha256"] == sha

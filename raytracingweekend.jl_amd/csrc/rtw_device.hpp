@@ -171,7 +171,8 @@ __device__ __forceinline__ void sphere_disc_n(T cx, T cy, T cz, T r2, [[maybe_un
     } else {
         half_b = (ocx * d.x + ocy * d.y) + ocz * d.z;                       // src/hit.jl:16
         const T ococ = (ocx * ocx + ocy * ocy) + ocz * ocz;
-        const T c = NUM == NUM_REFERENCE_FMA2 ? t_fma(-r, r, ococ) : ococ - r2;   // :17
+        // (:17; a PADDING row carries r^2 = -1e30 in the hot array and an arbitrary radius in the cold one: it must stay a miss in every mode)
+        const T c = (NUM == NUM_REFERENCE_FMA2 && !(r2 < T(0))) ? t_fma(-r, r, ococ) : ococ - r2;
         if constexpr (NUM == NUM_REFERENCE) disc = half_b * half_b - c;     // :18 (a == 1)
         else disc = t_fma(half_b, half_b, -c);
     }
@@ -778,7 +779,7 @@ __device__ unsigned g_cand_hist[8192];
 // Walk n entries of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
 struct NoOrig {};
 template <typename T, bool WITH_R, typename SRC, typename ORIG = NoOrig>
-__device__ __forceinline__ void resolve_pairs_impl(int num, SRC src, const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
+__device__ __forceinline__ void resolve_pairs_impl(int num, SRC src, [[maybe_unused]] const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
     constexpr bool CULLED = !__is_same(ORIG, NoOrig);      // device order != the caller's order: ties go by orig[], the key carries both
     constexpr unsigned G = RTW_SCAN_GROUP;
     using V4 = typename Vec4<T>::type;
@@ -835,10 +836,10 @@ __device__ __forceinline__ void resolve_pairs_impl(int num, SRC src, const typen
 }
 
 // (NUM_REFERENCE_FMA2 reads the radius from mat0: its own copy of the loop, so that the other modes keep their registers)
-template <typename T, typename SRC, typename ORIG = NoOrig>
-__device__ __forceinline__ void resolve_pairs(int num, SRC src, const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
-    if (num == NUM_REFERENCE_FMA2) resolve_pairs_impl<T, true>(num, src, rad, o, d, tmin, ws, n, lane, orig);
-    else resolve_pairs_impl<T, false>(num, src, rad, o, d, tmin, ws, n, lane, orig);
+template <typename T, typename SRC, typename RAD, typename ORIG = NoOrig>
+__device__ __forceinline__ void resolve_pairs(int num, SRC src, RAD rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
+    if (num == NUM_REFERENCE_FMA2) resolve_pairs_impl<T, true>(num, src, rad(), o, d, tmin, ws, n, lane, orig);
+    else resolve_pairs_impl<T, false>(num, src, nullptr, o, d, tmin, ws, n, lane, orig);
 }
 
 // Closest hit for the rays of a whole wave (every lane calls it, convergently; has_ray = this lane has a ray).
@@ -850,7 +851,8 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
                                               const WaveScratch &ws, unsigned lane, CLK &&clk = NoClock(),
                                               const MfmaCull *mc = nullptr, ORIG orig = ORIG()) {
     constexpr bool CULLED = !__is_same(ORIG, NoOrig);
-    const typename Vec4<T>::type *rad = CULLED ? (const typename Vec4<T>::type *)mc->mat0 : w.mat0;      // radii (mat0[i].x), in the order of `src`: NUM_REFERENCE_FMA2 only
+    // radii (mat0[i].x) in the order of `src`: read by NUM_REFERENCE_FMA2 only -- fetched from the kernel arguments where that mode needs them, not held across the scan
+    auto rad = [&]() -> const typename Vec4<T>::type * { if constexpr (CULLED) return (const typename Vec4<T>::type *)mc->mat0; else return w.mat0; };
     // ---- ray features (binary32) ----
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     const float s2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -945,7 +947,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             const V4 sg = src[si];
             T hb_, disc_, root_ = 0;
             T rr_ = T(0);
-            if (w.numerics == NUM_REFERENCE_FMA2) rr_ = rad[si].x;
+            if (w.numerics == NUM_REFERENCE_FMA2) rr_ = rad()[si].x;
             sphere_disc<T>(w.numerics, sg.x, sg.y, sg.z, sg.w, rr_, o, d, hb_, disc_);
             if (has_ray && sphere_root<T>(hb_, disc_, tmin, (T)__builtin_huge_val(), root_)) {
                 unsigned tie = (unsigned)si;                       // larger = later in the caller's list (resolve_pairs)

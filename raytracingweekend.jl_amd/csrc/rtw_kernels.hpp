@@ -327,10 +327,13 @@ __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned la
     if (lane == 0) S->job = g;
 }
 
-template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL, bool MFMA = false>
+// NUMK >= 0: the numerics mode is fixed at compile time (the launcher picks such an instance for the default mode of the headline
+// variants: the other modes' code and their scalar state are then not in the kernel at all); NUMK < 0: the mode of the arguments.
+template <typename T, bool PROFILE, bool LDS_SCENE, bool CULL, bool MFMA = false, int NUMK = -1>
 __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void trace_kernel(KParams P_arg, Camera<T> cam_arg, DevScene<T> scene,
                                                    CullScene<T> cull, T *__restrict__ out, DevCounters *ctr) {
     using V4 = typename Vec4<T>::type;
+    if constexpr (NUMK >= 0) { scene.numerics = NUMK; cull.numerics = NUMK; }
     const unsigned lane = lane_id();
     // LDS: [per-lane candidate lists, stride 256][job slots, ticket, camera][scene geom copy (LDS_SCENE only)]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -80,6 +80,9 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     else if (mfma) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false, true> : (kern_t)rtw::trace_kernel<T, false, false, false, true>;
     else if (phase_profile) kern = lds_scene ? (kern_t)rtw::trace_kernel<T, true, true, false> : (kern_t)rtw::trace_kernel<T, true, false, false>;
     else kern = lds_scene ? (kern_t)rtw::trace_kernel<T, false, true, false> : (kern_t)rtw::trace_kernel<T, false, false, false>;
+    // the default numerics mode of the headline variants (scene in LDS, matrix pipe): an instance with the mode fixed at compile time
+    if (S.numerics == rtw::NUM_REFERENCE && lds_scene && mfma && !phase_profile)
+        kern = cull ? (kern_t)rtw::trace_kernel<T, false, true, true, true, rtw::NUM_REFERENCE> : (kern_t)rtw::trace_kernel<T, false, true, false, true, rtw::NUM_REFERENCE>;
     // The ray-pool kernel (rtw_pool.hpp; opt-in: RTW_FLAG_RAY_POOL, or RTW_POOL=1 in the environment for A/B runs): Float32 plain
     // scans on the matrix pipe, when the pool, the rings and the scene copy fit the 160 KB of LDS of a CU (one workgroup of
     // RTW_POOL_W waves per CU); everything else runs the lane-loop kernel above.

@@ -231,6 +231,7 @@ def test_llvm_contraction_experiment():
     assert r.returncode == 0, r.stderr
     assert "disc_julia: fused multiply-adds: 0" in r.stdout and "disc_fastsq: fused multiply-adds: 2" in r.stdout, r.stdout
     assert "vfnmadd231ss" in r.stdout and "vfmsub231ss" in r.stdout
+    assert "root_julia: vsqrtss" in r.stdout and "vrsqrt" not in r.stdout           # sqrt_fast stays the IEEE square root (src/hit.jl:20)
 
 
 def test_c_host_example_compiles_and_links(tmp_path):

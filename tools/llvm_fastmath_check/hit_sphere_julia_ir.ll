@@ -44,4 +44,13 @@ define float @disc_fastsq(float %ox, float %oy, float %oz, float %cx, float %cy,
   %disc = fsub fast float %hb2, %c
   ret float %disc
 }
+; src/hit.jl:20-23: sqrtd = sqrt_fast(discriminant) -> `call fast float @llvm.sqrt.f32`; root = (-half_b - sqrtd) / a with a = 1
+define float @root_julia(float %hb, float %disc) {
+  %s = call fast float @llvm.sqrt.f32(float %disc)
+  %n = fneg fast float %hb
+  %r = fsub fast float %n, %s
+  %q = fdiv fast float %r, 1.0
+  ret float %q
+}
+declare float @llvm.sqrt.f32(float)
 declare float @llvm.powi.f32.i32(float, i32)
