@@ -712,6 +712,25 @@ typedef _Float16 rtw_h8 __attribute__((ext_vector_type(8)));
 typedef float rtw_f16v __attribute__((ext_vector_type(16)));
 
 // group cull on the matrix pipe: operands in the cull layout's device order, one binary32 box per block of 32 (lo.xyz, -, hi.xyz, -)
+// The block vote of the group cull (hit_world_mfma<.., CULLED>), per RAY and for 32 blocks at once.  A block can be touched when its box
+// overlaps the bounds [lo, hi] of the clipped ray on every axis: lo_b <= hi and hi_b >= lo.  Each axis is cut into RTW_CULL_BINS bins over
+// the small class's box (the outer bins reach to infinity); two tables per axis hold, per bin, the 32-bit set of the blocks with
+// lo_b <= (upper edge of the bin) and of those with hi_b >= (lower edge): six look-ups and five ANDs give the set of blocks the ray's
+// bounds can overlap -- a superset of the exact box test by at most one bin width per side.  The sets of a half wave are ORed on the DPP
+// network (4 steps): that is the whole vote, once per scan and group of 32 blocks, instead of 10 VALU instructions per (scan, block).
+// Tables (uint32, behind the boxes: box + 8 (blocks + 1)), per group of 32 blocks RTW_CULL_TAB_WORDS words:
+//     [axis][0: lo_b <= edge, indexed by the bin of hi | 1: hi_b >= edge, indexed by the bin of lo][bin], then {BIG blocks, live blocks, 0, 0}
+// (BIG: touched by every ray; live: what a ray without the filter touches; dead blocks are in no set).
+#define RTW_CULL_BINS 64
+#ifndef RTW_CULL_SPLIT
+#define RTW_CULL_SPLIT 0     // 1: the clipped segment is looked up as two halves (experiment)
+#endif
+#define RTW_CULL_TAB_WORDS (6 * RTW_CULL_BINS + 4)
+__host__ __device__ inline int cull_tab_words(int blocks) { return ((blocks + 31) / 32 > 0 ? (blocks + 31) / 32 : 1) * RTW_CULL_TAB_WORDS; }
+struct CullGrid {
+    float inv[3], off[3];          // bin of a coordinate p on axis k: floor(p inv[k] + off[k]) clamped to 0 .. RTW_CULL_BINS - 1
+};
+
 struct MfmaCull {
     const uint4 *ops;
     const float *box;
@@ -720,6 +739,8 @@ struct MfmaCull {
     const void *mat0;     // the cold rows in this (device) order: mat0[i].x = the radius (NUM_REFERENCE_FMA2)
     float glo[3], ghi[3]; // the box of the whole small class (the union of its blocks' boxes): a ray is clipped against it ONCE per scan
     int n_huge, huge[2];  // huge spheres (device order), tested in-lane like DevScene::huge
+    CullGrid grid;        // the block vote: bins ...
+    const unsigned *tab;  // ... and tables (global memory, or the workgroup's copy in LDS)
 };
 
 struct WaveScratch {
@@ -983,13 +1004,13 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     // test; a ray running along the layer gets loose bounds -- conservative, never wrong.  A ray that misses the small class's box
     // touches no block of it; a ray that does not use the filter (not ok) touches every block; the BIG class's blocks carry infinite
     // bounds (never skipped); lanes without a ray are masked out of the vote.
-    [[maybe_unused]] float pming[3] = {0, 0, 0}, pmaxg[3] = {0, 0, 0};
-    [[maybe_unused]] unsigned long long ray_mask = 0, all_mask = 0;
-    typedef const float __attribute__((address_space(4))) *cfptr;
-    [[maybe_unused]] cfptr gbox = nullptr;
+    [[maybe_unused]] unsigned bin_lo[3] = {0, 0, 0}, bin_hi[3] = {0, 0, 0};     // the bins of the ray's bounds
+#if RTW_CULL_SPLIT
+    [[maybe_unused]] unsigned bin_lo2[3] = {0, 0, 0}, bin_hi2[3] = {0, 0, 0};   // (second half of the clipped segment)
+#endif
+    [[maybe_unused]] bool cells_ok = false;                                       // the ray uses the filter and meets the small class's box
+    [[maybe_unused]] unsigned flag_word = 0;                                      // which word behind a group's tables the ray ORs in: BIG / live / 0
     if constexpr (CULLED) {
-        gbox = (cfptr)(uintptr_t)mc->box;
-        ray_mask = __ballot(has_ray);
         const float ex = ox - mc->cs[0], ey = oy - mc->cs[1], ez = oz - mc->cs[2];
         const float eps_p = (s2 > 1.0f ? s2 - 1.0f : 0.0f) + 2.4e-7f * s2;
         // (hardware approximations v_sqrt_f32 / v_rcp_f32, 1 ulp: m is inflated by 2^-10 for them, and the reciprocals only place the end
@@ -1013,13 +1034,36 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         // (for a ray that uses the filter every quantity above is finite: |o_k| <= mf_o_max, |d|^2 <= 1.0009, |1 / d_k| <= 1e9; the others are
         //  handled by the mask below, whatever their bounds came out as)
         const bool hits_class = tf >= tn;
-        const float big = 3.0e38f;
-        pming[0] = __builtin_fminf(ax, bx) - m2; pming[1] = __builtin_fminf(ay, by) - m2; pming[2] = __builtin_fminf(az, bz) - m2;
-        pmaxg[0] = __builtin_fmaxf(ax, bx) + m2; pmaxg[1] = __builtin_fmaxf(ay, by) + m2; pmaxg[2] = __builtin_fmaxf(az, bz) + m2;
-        if (!hits_class) { pming[0] = pming[1] = pming[2] = big; pmaxg[0] = pmaxg[1] = pmaxg[2] = -big; }      // no block of the small class (the BIG class's bounds are +-inf: still touched)
-        all_mask = __ballot(has_ray && !ok);                 // rays that do not use the filter touch EVERY block
+        const float lo3[3] = {__builtin_fminf(ax, bx) - m2, __builtin_fminf(ay, by) - m2, __builtin_fminf(az, bz) - m2};
+        const float hi3[3] = {__builtin_fmaxf(ax, bx) + m2, __builtin_fmaxf(ay, by) + m2, __builtin_fmaxf(az, bz) + m2};
+        // the bins of the bounds on each axis (inv >= 0); a ray that misses the small class's box is in no block's set (the BIG class comes
+        // in through its flag word), one that does not use the filter takes every live block
+        const CullGrid &G = mc->grid;
+        auto binf = [](float u) { return (unsigned)__builtin_amdgcn_fmed3f(u, 0.0f, (float)RTW_CULL_BINS - 0.5f); };       // (NaN -> 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bin_lo[k] = binf(__builtin_fmaf(lo3[k], G.inv[k], G.off[k]));
+            bin_hi[k] = binf(__builtin_fmaf(hi3[k], G.inv[k], G.off[k]));
+        }
+#if RTW_CULL_SPLIT
+        {   // the two halves of the segment, each with its own bounds: [a, mid] and [mid, b]
+            const float tm = 0.5f * (tn + tf);
+            const float mid[3] = {__builtin_fmaf(tm, dx, ox), __builtin_fmaf(tm, dy, oy), __builtin_fmaf(tm, dz, oz)};
+            const float pa3[3] = {ax, ay, az}, pb3[3] = {bx, by, bz};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                bin_lo[k] = binf(__builtin_fmaf(__builtin_fminf(pa3[k], mid[k]) - m2, G.inv[k], G.off[k]));
+                bin_hi[k] = binf(__builtin_fmaf(__builtin_fmaxf(pa3[k], mid[k]) + m2, G.inv[k], G.off[k]));
+                bin_lo2[k] = binf(__builtin_fmaf(__builtin_fminf(pb3[k], mid[k]) - m2, G.inv[k], G.off[k]));
+                bin_hi2[k] = binf(__builtin_fmaf(__builtin_fmaxf(pb3[k], mid[k]) + m2, G.inv[k], G.off[k]));
+            }
+        }
+#endif
+        cells_ok = ok && hits_class;
+        flag_word = 6u * RTW_CULL_BINS + (has_ray ? (ok ? 0u : 1u) : 2u);
     }
-    uint4 A1 = pa[0], A2 = pa[64];
+    uint4 A1 = {0u, 0u, 0u, 0u}, A2 = {0u, 0u, 0u, 0u};
+    if constexpr (!CULLED) { A1 = pa[0]; A2 = pa[64]; }
     // Wave priority: low inside the block loop, raised for everything else (pass 2 and the divergent phases of the lane loop are
     // chains of dependent LDS / VALU instructions; a wave in the block loop issues a 32-cycle MFMA pair and waits for it
     // anyway).  Measured at Float32: 372.1 -> 368.0 ms on one box, 361.8 -> 359.9 on a faster one, group cull 345.6 -> 343.0; which of
@@ -1028,24 +1072,48 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     // rest low -- so that is what it gets.
     constexpr bool use_prio = RTW_SCAN_PRIO != 0;
     if (use_prio) __builtin_amdgcn_s_setprio(sizeof(T) == 4 ? 0 : 1);
-    for (int blk = 0; blk < n_blocks; ++blk) {
+    // The blocks are visited in groups of 32 (CULLED: every lane looks its ray's set of blocks up, the sets of a half wave are ORed, and
+    // only the blocks some ray can touch are visited; otherwise one group = every block in turn).
+    for (int base = 0; base < n_blocks; base += CULLED ? 32 : n_blocks) {
+    [[maybe_unused]] unsigned vote0 = 0, vote1 = 0, todo = 0;
+    int blk = base;
+    if constexpr (CULLED) {
+        const unsigned *t = mc->tab + (base >> 5) * RTW_CULL_TAB_WORDS;
+        unsigned mine = (t[0 * RTW_CULL_BINS + bin_hi[0]] & t[1 * RTW_CULL_BINS + bin_lo[0]]) & (t[2 * RTW_CULL_BINS + bin_hi[1]] & t[3 * RTW_CULL_BINS + bin_lo[1]]) &
+                        (t[4 * RTW_CULL_BINS + bin_hi[2]] & t[5 * RTW_CULL_BINS + bin_lo[2]]);
+#if RTW_CULL_SPLIT
+        mine |= (t[0 * RTW_CULL_BINS + bin_hi2[0]] & t[1 * RTW_CULL_BINS + bin_lo2[0]]) & (t[2 * RTW_CULL_BINS + bin_hi2[1]] & t[3 * RTW_CULL_BINS + bin_lo2[1]]) &
+                (t[4 * RTW_CULL_BINS + bin_hi2[2]] & t[5 * RTW_CULL_BINS + bin_lo2[2]]);
+#endif
+        mine = (cells_ok ? mine : 0u) | t[flag_word];
+        // OR over the 16 lanes of a row (xor butterfly on the DPP network), then the two rows of each half wave
+        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x141, 0xf, 0xf, true);    // row_half_mirror
+        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x140, 0xf, 0xf, true);    // row_mirror
+        vote0 = (unsigned)__builtin_amdgcn_readlane((int)mine, 0) | (unsigned)__builtin_amdgcn_readlane((int)mine, 16);
+        vote1 = (unsigned)__builtin_amdgcn_readlane((int)mine, 32) | (unsigned)__builtin_amdgcn_readlane((int)mine, 48);
+        todo = vote0 | vote1;
+        clk.count(7, (unsigned)(n_blocks - base < 32 ? n_blocks - base : 32));
+        clk.count(6, (unsigned)((n_blocks - base < 32 ? n_blocks - base : 32) - __popc(todo)));
+        if (!todo) continue;
+        blk = base + (int)__builtin_ctz(todo);
+        todo &= todo - 1u;
+        A1 = pa[blk * 128]; A2 = pa[blk * 128 + 64];
+    }
+    for (bool more = true; more;) {
+        const int cur = blk;                                   // (this iteration's block; `blk` becomes the next one)
         [[maybe_unused]] bool do_half0 = true, do_half1 = true;          // (wave-uniform) group cull: which ray halves of the wave can touch this block
         if constexpr (CULLED) {
-            const float lx = gbox[8 * blk], ly = gbox[8 * blk + 1], lz = gbox[8 * blk + 2];
-            const float hx = gbox[8 * blk + 4], hy = gbox[8 * blk + 5], hz = gbox[8 * blk + 6];
-            // (the block's bounds are stored grown by nothing; m is on the ray's side: pming / pmaxg)
-            const float sep = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lx - pmaxg[0], ly - pmaxg[1]), lz - pmaxg[2]),
-                                              __builtin_fmaxf(__builtin_fmaxf(pming[0] - hx, pming[1] - hy), pming[2] - hz));
-            const unsigned long long touch = (__ballot(!(sep > 0.0f)) & ray_mask) | all_mask;
-            clk.count(7, 1u);
-            if (!touch) {
-                clk.count(6, 1u);
-                A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];      // (keeps the operand pipeline going)
-                continue;
-            }
             // lanes l and l + 32 hold the same 32 rays of a half wave: the two MFMA pairs of a block are the two RAY halves -- each is skipped by itself
-            do_half0 = (unsigned)touch != 0u;
-            do_half1 = (unsigned)(touch >> 32) != 0u;
+            do_half0 = ((vote0 >> (cur - base)) & 1u) != 0u;
+            do_half1 = ((vote1 >> (cur - base)) & 1u) != 0u;
+            more = todo != 0u;
+            blk = more ? base + (int)__builtin_ctz(todo) : cur + 1;     // (the operand array has one block of padding at the end)
+            todo &= todo - 1u;
+        } else {
+            blk = cur + 1;
+            more = blk < n_blocks;
         }
         unsigned mask = 0;
         bool any_cand = false;                               // (wave-uniform)
@@ -1131,7 +1199,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
 #endif
 #if RTW_SCAN_CMP
-            if ((!CULLED || do_half0) && !(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 0u, blk); }
+            if ((!CULLED || do_half0) && !(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 0u, cur); }
 #else
             if ((CULLED && !do_half0) || (RTW_SCAN_SKIP && none(Wv))) mask = (1u << HB) - 1u;          // all negative
             else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }      // (the asm keeps it a real branch: no if-conversion)
@@ -1143,13 +1211,13 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             rtw_f16v Wv = zero;
             if (!CULLED || do_half1) Wv = filter_pair(A1, A2, B1[1], B2[1]);
             __builtin_amdgcn_sched_barrier(0);
-            A1 = pa[(blk + 1) * 128]; A2 = pa[(blk + 1) * 128 + 64];
+            A1 = pa[blk * 128]; A2 = pa[blk * 128 + 64];
             __builtin_amdgcn_sched_barrier(0);
 #ifdef RTW_DUP_EVAL
             { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
 #endif
 #if RTW_SCAN_CMP
-            if ((!CULLED || do_half1) && !(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 16u, blk); }
+            if ((!CULLED || do_half1) && !(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 16u, cur); }
 #else
             if ((CULLED && !do_half1) || (RTW_SCAN_SKIP && none(Wv))) mask = (mask << HB) | ((1u << HB) - 1u);
             else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }
@@ -1171,7 +1239,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             clk.count(7, 1u);
             if (!__any(m != 0u)) clk.count(6, 1u);
         }
-        const unsigned code0 = lane_const + (unsigned)blk * 32u + (NB - 1u);      // entry = recording lane << 16 | block << 5 | b
+        const unsigned code0 = lane_const + (unsigned)cur * 32u + (NB - 1u);      // entry = recording lane << 16 | block << 5 | b
 #ifdef RTW_DUP_EXTRACT   // instruction/time probe: the extraction loop twice (the first run writes the same entries)
         { unsigned m2 = m, t2 = total;   // (probe)
           for (;;) {
@@ -1204,6 +1272,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             total += (unsigned)__popcll(act);
         }
         clk.lap(4);
+    }
     }
     if (use_prio) __builtin_amdgcn_s_setprio(sizeof(T) == 4 ? 1 : 0);
     resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig);
@@ -1275,11 +1344,12 @@ template <typename T> struct CullScene {
     float mf_glo[3], mf_ghi[3];            //   ... and the box of the whole small class (the union of those boxes; an empty class: lo > hi)
     int mf_blocks;
     int n_huge, huge[2];                   // huge spheres in this order (see DevScene::huge)
+    CullGrid grid;                         // the block vote (tables behind mf_box)
     int numerics;                          // NUM_* (see DevScene::numerics)
 };
 template <typename T> __host__ __device__ inline MfmaCull mfma_cull_of(const CullScene<T> &c) {
     return MfmaCull{c.mf_ops, c.mf_box, c.mf_blocks, {(float)c.cs[0], (float)c.cs[1], (float)c.cs[2]}, (float)c.rs * 1.000001f + 1e-30f, (const void *)c.mat0,
-                    {c.mf_glo[0], c.mf_glo[1], c.mf_glo[2]}, {c.mf_ghi[0], c.mf_ghi[1], c.mf_ghi[2]}, c.n_huge, {c.huge[0], c.huge[1]}};
+                    {c.mf_glo[0], c.mf_glo[1], c.mf_glo[2]}, {c.mf_ghi[0], c.mf_ghi[1], c.mf_ghi[2]}, c.n_huge, {c.huge[0], c.huge[1]}, c.grid, reinterpret_cast<const unsigned *>(c.mf_box + 8 * (c.mf_blocks + 1))};
 }
 template <typename T> __host__ __device__ inline int cull_exact_count(const CullScene<T> &c) { return c.n_groups_pad * RTW_CULL_GS + ((c.n_big + 31) / 32) * 32; }   // (allocated in whole blocks of 32: dead slots behind the BIG class)
 

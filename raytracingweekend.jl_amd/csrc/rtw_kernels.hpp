@@ -356,12 +356,18 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         pool_rng = reinterpret_cast<ulonglong2 *>(cells + mfma_cell_bytes<T>() - 4 * 64 * 16) + wv * 64;
     }
     unsigned short *lds_orig = reinterpret_cast<unsigned short *>(lds_geom + (CULL ? cull_exact_count(cull) : 0));
+    // (CULL on the matrix pipe: the tables of the block vote behind the index list)
+    [[maybe_unused]] unsigned *lds_tab = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(lds_orig) + (CULL ? ((size_t)cull_exact_count(cull) * sizeof(unsigned short) + 15) / 16 * 16 : 0));
     if (threadIdx.x < P_arg.n_slots) { JobSlot *S0 = sh->slot(threadIdx.x, P_arg.slot_stride); S0->ready_seq = RTW_SLOT_FREE; S0->job = 0u; }
     if (threadIdx.x == 0) { sh->ticket = 0u; sh->fin_waves = 0u; sh->fin_segments = 0ull; sh->fin_samples = 0ull; sh->jobs.jc = 0ull; sh->jobs.jc_lock = 0u; sh->jobs.queue_off = 0u; sh->jobs.last_g = 0u; sh->cam = cam_arg; sh->P = P_arg; }
     const KParams &P = sh->P;
     if (LDS_SCENE) {
         if (CULL) stage_cull_scene<T>(cull, lds_geom, lds_orig);
         else stage_scene<T>(scene, lds_geom);
+        if constexpr (CULL && MFMA) {
+            const unsigned *gt = reinterpret_cast<const unsigned *>(cull.mf_box + 8 * (cull.mf_blocks + 1));
+            for (int i = threadIdx.x; i < cull_tab_words(cull.mf_blocks); i += blockDim.x) lds_tab[i] = gt[i];
+        }
     }
     __syncthreads();
 
@@ -395,7 +401,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         int idx = -1;
         if constexpr (MFMA && CULL) {
             if (__any(has_ray)) {
-                const MfmaCull mc = mfma_cull_of(cull);
+                MfmaCull mc = mfma_cull_of(cull);
+                if (LDS_SCENE) mc.tab = lds_tab;
                 if (LDS_SCENE) idx = hit_world_mfma<T>(scene, (const V4 *)lds_geom, ro, rd, has_ray, (T)1e-4, t_hit, ws, lane, clk, &mc, (const unsigned short *)lds_orig);
                 else idx = hit_world_mfma<T>(scene, cull.exact, ro, rd, has_ray, (T)1e-4, t_hit, ws, lane, clk, &mc, cull.orig);
             }

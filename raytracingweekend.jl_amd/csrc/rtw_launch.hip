@@ -62,13 +62,15 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     rtw::CullScene<T> CS = cull_scene_of<T>(scene);
     CS.numerics = S.numerics;
     const size_t n_cull = (size_t)rtw::cull_exact_count(CS);
-    const size_t geom_bytes = cull ? n_cull * sizeof(V4) + ((n_cull * sizeof(unsigned short) + 15) / 16) * 16
-                                   : (size_t)rtw::scene_geom_alloc(scene->n, scene->n_pad) * sizeof(V4);
-    const bool lds_scene = geom_bytes <= RTW_LDS_SCENE_MAX_BYTES;
     // the plain scan runs pass 1 on the matrix pipe (RTW_SCAN=valu: the all-VALU scan, for A/B measurements)
     static const bool force_valu = aid_env("RTW_SCAN") != nullptr && strcmp(aid_env("RTW_SCAN"), "valu") == 0;
     // (group cull: on the matrix pipe too when the scene has the operands; RTW_FLAG_SCAN_VALU selects the all-VALU cull scan)
     const bool mfma = (cull ? scene->c_mf_ops != nullptr : scene->mf_ops != nullptr) && !force_valu && !(p->flags & RTW_FLAG_SCAN_VALU);
+    // (group cull on the matrix pipe: the tables of the block vote travel with the scene copy)
+    const size_t geom_bytes = cull ? n_cull * sizeof(V4) + ((n_cull * sizeof(unsigned short) + 15) / 16) * 16 +
+                                         (mfma ? (size_t)rtw::cull_tab_words(scene->c_mf_blocks) * sizeof(unsigned) : 0)
+                                   : (size_t)rtw::scene_geom_alloc(scene->n, scene->n_pad) * sizeof(V4);
+    const bool lds_scene = geom_bytes <= RTW_LDS_SCENE_MAX_BYTES;
     const size_t lds_bytes = list_bytes + shared_bytes + (mfma ? rtw::mfma_cell_bytes<T>() : 0) + (lds_scene ? geom_bytes : 0);
     typedef void (*kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, rtw::CullScene<T>, T *, rtw::DevCounters *);
     kern_t kern;

@@ -67,6 +67,54 @@ def test_t3_sees_the_bias_between_numerics_modes(oracle, rtw):
             assert abs(sa.segments / sc.segments - 1.0) < 2e-3
 
 
+# ---- the block vote of the group cull (rtw_device.hpp CullGrid: bins + per-bin block sets, one look-up per ray and scan) ------------
+def _flat_scene(T, cx, cy, cz, r, seed):
+    rng = np.random.default_rng(seed)
+    n = len(cx)
+    kind = rng.integers(0, 3, n).astype(np.int32)
+    param = np.where(kind == 2, 1.5, np.where(kind == 1, rng.uniform(0, 0.5, n), 0.0)).astype(T)
+    return dict(n=n, cx=np.asarray(cx, T), cy=np.asarray(cy, T), cz=np.asarray(cz, T), r=np.asarray(r, T), kind=kind,
+                ar=rng.uniform(0.2, 1, n).astype(T), ag=rng.uniform(0.2, 1, n).astype(T), ab=rng.uniform(0.2, 1, n).astype(T), param=param)
+
+
+def _vote_scenes(T):
+    rng = np.random.default_rng(23)
+    out = {}
+    # 1 100 spheres: two groups of 32 blocks, scene copy AND both groups' tables in LDS
+    n = 1100
+    out["two_groups_lds"] = _flat_scene(T, rng.uniform(-9, 9, n), rng.uniform(-0.3, 0.3, n), rng.uniform(-14, -2, n), rng.uniform(0.05, 0.25, n), 1)
+    # a lattice whose sphere boxes end exactly on bin edges: extent 16 over 64 bins = 0.25 per bin, centres on multiples of 0.5, r = 0.25
+    gx, gz = np.meshgrid(np.arange(-8, 8.01, 0.5), np.arange(-18, -2 + 0.01, 0.5))
+    out["on_bin_edges"] = _flat_scene(T, gx.ravel(), np.zeros(gx.size), gz.ravel(), np.full(gx.size, 0.25), 2)
+    # every small sphere in one plane and of one size (one axis of the class's box has the extent of a diameter), plus a ground sphere (huge: in-lane)
+    n = 300
+    out["flat_layer"] = _flat_scene(T, np.r_[rng.uniform(-6, 6, n), 0.0], np.r_[np.full(n, 0.2), -1000.0], np.r_[rng.uniform(-12, -2, n), -6.0],
+                                    np.r_[np.full(n, 0.2), 1000.0], 3)
+    # a sparse class: two far-apart clumps (most bins empty) and a few BIG spheres
+    n = 200
+    cx = np.r_[rng.uniform(-60, -58, n), rng.uniform(58, 60, n), [0.0, 3.0, -3.0]]
+    cz = np.r_[rng.uniform(-40, -38, n), rng.uniform(-12, -10, n), [-8.0, -8.0, -8.0]]
+    out["two_clumps"] = _flat_scene(T, cx, np.r_[rng.uniform(-1, 1, 2 * n), [0.0, 0.0, 0.0]], cz, np.r_[rng.uniform(0.1, 0.4, 2 * n), [1.5, 1.0, 1.0]], 4)
+    # all spheres concentric (zero extent of the centres; boxes differ by the radii only)
+    n = 40
+    out["concentric"] = _flat_scene(T, np.zeros(n), np.zeros(n), np.full(n, -6.0), np.linspace(0.5, 2.5, n), 5)
+    return out
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_block_vote_never_skips_a_block_a_ray_can_hit(oracle, T):
+    """group cull (flags 1: table vote on the matrix pipe) == plain scan == oracle on scenes built against the vote: block sets of two
+    groups, boxes ending on bin edges, a flat class, mostly empty bins, concentric spheres; wide and narrow cameras"""
+    g0 = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
+    cam_wide = {k: np.asarray(v).astype(T) for k, v in g0["cam"].items()}
+    for name, flat in _vote_scenes(T).items():
+        g = dict(g0, flat=flat, cam=cam_wide, image=np.zeros((1, 1, 3), T))
+        ref, ost = oracle.render(flat, g["cam"], 96, 54, 4, T=T, max_depth=12, seed=5, n_chunks=2)
+        for flags in (1, 0, 5):
+            img, st = gpu_render(g, width=96, height=54, spp=4, n_chunks=2, max_depth=12, seed=5, flags=flags)
+            assert np.array_equal(img, ref) and st.segments == ost["segments"], (name, flags)
+
+
 # ---- test aids need the master switch ------------------------------------------------------------------------------------------
 _AID_PROBE = r"""
 import json, sys
