@@ -721,9 +721,9 @@ typedef float rtw_f16v __attribute__((ext_vector_type(16)));
 // Tables (uint32, behind the boxes: box + 8 (blocks + 1)), per group of 32 blocks RTW_CULL_TAB_WORDS words:
 //     [axis][0: lo_b <= edge, indexed by the bin of hi | 1: hi_b >= edge, indexed by the bin of lo][bin], then {BIG blocks, live blocks, 0, 0}
 // (BIG: touched by every ray; live: what a ray without the filter touches; dead blocks are in no set).
+// 64 bins: one table = 64 words = one word per LDS bank, any 64 look-ups are conflict-free; 128 bins measured 8 % SLOWER (317 vs 293 ms).
+#ifndef RTW_CULL_BINS
 #define RTW_CULL_BINS 64
-#ifndef RTW_CULL_SPLIT
-#define RTW_CULL_SPLIT 0     // 1: the clipped segment is looked up as two halves (experiment)
 #endif
 #define RTW_CULL_TAB_WORDS (6 * RTW_CULL_BINS + 4)
 __host__ __device__ inline int cull_tab_words(int blocks) { return ((blocks + 31) / 32 > 0 ? (blocks + 31) / 32 : 1) * RTW_CULL_TAB_WORDS; }
@@ -865,8 +865,8 @@ __device__ __forceinline__ void resolve_pairs(int num, SRC src, RAD rad, V3<T> o
 
 // Closest hit for the rays of a whole wave (every lane calls it, convergently; has_ray = this lane has a ray).
 // With `mc` (group cull, RTW_FLAG_GROUP_CULL): the spheres come in the cull layout's device order (src, orig), and a block of
-// 32 is skipped when NO ray of the wave can touch its box -- the slab test of hit_world_cull (same conservative margin, in
-// binary32 with the Float32 kappa for both precisions) per lane, then a wave-wide vote.  Returns the DEVICE index.
+// 32 is visited only when some ray of the half wave can touch its box (the conservative margin of hit_world_cull, in binary32 with
+// the Float32 kappa for both precisions): the table vote of CullGrid, once per scan.  Returns the DEVICE index.
 template <typename T, typename SRC, typename ORIG = NoOrig, typename CLK = NoClock>
 __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<T> o, V3<T> d, bool has_ray, T tmin, T &t_hit,
                                               const WaveScratch &ws, unsigned lane, CLK &&clk = NoClock(),
@@ -891,6 +891,84 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     const float fq[6] = {dx2 * dx, dy2 * dy, dz2 * dz, (dx2 + dx2) * dy, (dx2 + dx2) * dz, (dy2 + dy2) * dz};
     // a lane that is not ok: all features 0 and t1 = +-60000 (exact in f16): W = +-2^15 x 60000 for EVERY sphere
     const float tx = ok ? tq : (has_ray ? 60000.0f * 32768.0f : -60000.0f * 32768.0f);
+    const uint4 *pa = (CULLED ? mc->ops : w.mf_ops) + lane;
+    const int n_blocks = CULLED ? mc->blocks : w.mf_blocks;
+    // Group cull: the block vote.  A sphere of a block can only be hit if the RAY (t >= 0) meets the block's box grown by the margin m
+    // (hit_world_cull derives m).  Round 4 ran that slab test per (lane, block): 23 VALU instructions x 17 blocks, about what the skipped
+    // blocks saved.  Since round 5 the ray is clipped ONCE per scan against the box of the whole small class grown by m (the union of the
+    // blocks' boxes: every grown block box lies inside it), which leaves a segment [tn, tf] of the ray; every point of the ray inside any
+    // grown block box lies on that segment, hence inside the segment's axis-aligned bounds [pmin, pmax], and
+    //     the ray can touch block b  =>  lo_b - m <= pmax + delta  and  hi_b + m >= pmin - delta        on every axis
+    // with delta the rounding of tn, tf and the two end points (a few ulps of |o| + tf |d|: below 1e-6 of the distances m is proportional
+    // to with a factor >= 2^-8), covered by using m for it: lo3 = pmin - 2m, hi3 = pmax + 2m.  That test is not run per block: the bins
+    // of lo3 / hi3 index the tables of CullGrid, whose entries are the SETS of blocks passing each of the six comparisons (a superset: the
+    // bin's far edge stands for the coordinate); their AND is the ray's set, the OR over a half wave is the vote -- 6 look-ups per ray and
+    // scan instead of 10 instructions per (ray, block).  For the flat layer of small spheres of the reference's scenes the segment is
+    // short (the ray crosses the layer), so the bounds are tight; a ray running along the layer gets loose bounds -- conservative, never
+    // wrong.  A ray that misses the small class's box is in no block's set; one that does not use the filter (not ok) takes every live
+    // block and every ray the BIG class, through the flag words behind the tables; lanes without a ray contribute nothing.
+    // (a lambda run once per group of 32 blocks, from the ray itself: nothing of it -- bins, flags -- is held in registers across the block
+    //  loop; scenes of more than 1 024 spheres repeat the clip per group, 100 instructions against 32 blocks' work)
+    [[maybe_unused]] auto block_sets = [&](int base_, unsigned &v0_, unsigned &v1_) {
+        float cox = ox, coy = oy, coz = oz, cdx = dx, cdy = dy, cdz = dz, cs2 = s2;
+        __asm__ volatile("" : "+v"(cox), "+v"(coy), "+v"(coz), "+v"(cdx), "+v"(cdy), "+v"(cdz), "+v"(cs2));      // (not hoisted out of the group loop)
+        unsigned bin_lo[3], bin_hi[3];
+        const float ex = cox - mc->cs[0], ey = coy - mc->cs[1], ez = coz - mc->cs[2];
+        const float eps_p = (cs2 > 1.0f ? cs2 - 1.0f : 0.0f) + 2.4e-7f * cs2;
+        // (hardware approximations v_sqrt_f32 / v_rcp_f32, 1 ulp: m is inflated by 2^-10 for them, and the reciprocals only place the end
+        //  points of the clip, whose rounding the 2 m of slack covers a thousandfold -- the IEEE forms cost 65 instructions per scan)
+        const float m = 1.001f * (0.00390625f * (cs2 > 1.0f ? cs2 : 1.0f) + 2.0f * __builtin_amdgcn_sqrtf(eps_p)) *
+                        ((__builtin_amdgcn_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) + mc->rs) + 1.0f);
+        // 1 / d_k with |d_k| clamped to >= 1e-9 (moves the ray by < 1e-9 t): max on the magnitude, the sign copied back (v_max_f32 |x|, v_bfi_b32, v_rcp_f32)
+        auto safe_inv = [](float x) {
+            const float mag = __builtin_fmaxf(__builtin_fabsf(x), 1e-9f);
+            return __builtin_amdgcn_rcpf(__uint_as_float((__float_as_uint(mag) & 0x7fffffffu) | (__float_as_uint(x) & 0x80000000u)));
+        };
+        const float ix = safe_inv(cdx), iy = safe_inv(cdy), iz = safe_inv(cdz);
+        const float x0 = ((mc->glo[0] - m) - cox) * ix, x1 = ((mc->ghi[0] + m) - cox) * ix;
+        const float y0 = ((mc->glo[1] - m) - coy) * iy, y1 = ((mc->ghi[1] + m) - coy) * iy;
+        const float z0 = ((mc->glo[2] - m) - coz) * iz, z1 = ((mc->ghi[2] + m) - coz) * iz;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1)), 0.0f);
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+        const float m2 = m + m;
+        const float ax = __builtin_fmaf(tn, cdx, cox), ay = __builtin_fmaf(tn, cdy, coy), az = __builtin_fmaf(tn, cdz, coz);
+        const float bx = __builtin_fmaf(tf, cdx, cox), by = __builtin_fmaf(tf, cdy, coy), bz = __builtin_fmaf(tf, cdz, coz);
+        // (for a ray that uses the filter every quantity above is finite: |o_k| <= mf_o_max, |d|^2 <= 1.0009, |1 / d_k| <= 1e9; the others are
+        //  handled by the mask below, whatever their bounds came out as)
+        const bool hits_class = tf >= tn;
+        const float lo3[3] = {__builtin_fminf(ax, bx) - m2, __builtin_fminf(ay, by) - m2, __builtin_fminf(az, bz) - m2};
+        const float hi3[3] = {__builtin_fmaxf(ax, bx) + m2, __builtin_fmaxf(ay, by) + m2, __builtin_fmaxf(az, bz) + m2};
+        // the bins of the bounds on each axis (inv >= 0); a ray that misses the small class's box is in no block's set (the BIG class comes
+        // in through its flag word), one that does not use the filter takes every live block
+        const CullGrid &G = mc->grid;
+        auto binf = [](float u) {                                                                                          // (NaN -> 0)
+            const unsigned b = (unsigned)__builtin_amdgcn_fmed3f(u, 0.0f, (float)RTW_CULL_BINS - 0.5f);
+            __builtin_assume(b < (unsigned)RTW_CULL_BINS);      // (a 32-bit table offset: no 64-bit index pairs held across the block loop)
+            return b;
+        };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bin_lo[k] = binf(__builtin_fmaf(lo3[k], G.inv[k], G.off[k]));
+            bin_hi[k] = binf(__builtin_fmaf(hi3[k], G.inv[k], G.off[k]));
+        }
+        const bool cells_ok = ok && hits_class;
+        const unsigned flag_word = 6u * RTW_CULL_BINS + (has_ray ? (ok ? 0u : 1u) : 2u);     // the word behind the group's tables the ray ORs in: BIG / live / 0
+        const unsigned *t = mc->tab + (base_ >> 5) * RTW_CULL_TAB_WORDS;
+        unsigned mine = (t[0 * RTW_CULL_BINS + bin_hi[0]] & t[1 * RTW_CULL_BINS + bin_lo[0]]) & (t[2 * RTW_CULL_BINS + bin_hi[1]] & t[3 * RTW_CULL_BINS + bin_lo[1]]) &
+                        (t[4 * RTW_CULL_BINS + bin_hi[2]] & t[5 * RTW_CULL_BINS + bin_lo[2]]);
+        mine = (cells_ok ? mine : 0u) | t[flag_word];
+        // OR over the 16 lanes of a row (xor butterfly on the DPP network), then the two rows of each half wave
+        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x141, 0xf, 0xf, true);    // row_half_mirror
+        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x140, 0xf, 0xf, true);    // row_mirror
+        v0_ = (unsigned)__builtin_amdgcn_readlane((int)mine, 0) | (unsigned)__builtin_amdgcn_readlane((int)mine, 16);
+        v1_ = (unsigned)__builtin_amdgcn_readlane((int)mine, 32) | (unsigned)__builtin_amdgcn_readlane((int)mine, 48);
+    };
+    // (measured: running the first group's vote and the first operand fetch HERE, in front of the ray operands and the huge-sphere tests,
+    //  changes nothing -- 293.1 against 293.2 ms -- and costs a spilled register: the vote stays in the block loop's prologue)
+    uint4 A1 = {0u, 0u, 0u, 0u}, A2 = {0u, 0u, 0u, 0u};
+    if constexpr (!CULLED) { A1 = pa[0]; A2 = pa[64]; }
     // Lane (H, j) supplies slots 8H .. 8H + 7 of both MFMAs for ray j (first half wave: h = 0) / ray 32 + j (h = 1).  Every
     // lane makes, for ITS ray, the operand words of both lane groups; one v_permlane32_swap per word then hands each lane
     // group its words for both half waves:
@@ -989,81 +1067,6 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
 
     const unsigned lane_const = lane << 16;
     unsigned total = 0;                                   // wave-uniform
-    const uint4 *pa = (CULLED ? mc->ops : w.mf_ops) + lane;
-    const int n_blocks = CULLED ? mc->blocks : w.mf_blocks;
-    // Group cull: the per-ray side of the block vote.  A sphere of a block can only be hit if the RAY (t >= 0) meets the block's box grown
-    // by the margin m (hit_world_cull derives m).  Round 4 ran that slab test per (lane, block): 23 VALU instructions x 17 blocks, about
-    // what the skipped blocks saved.  Round 5: the ray is clipped ONCE per scan against the box of the whole small class grown by m
-    // (the union of the blocks' boxes: every grown block box lies inside it), which leaves a segment [tn, tf] of the ray; every point of
-    // the ray inside any grown block box lies on that segment, hence inside the segment's axis-aligned bounds [pmin, pmax].  Per block
-    // the vote is then the overlap of two boxes -- 6 subtractions and 3 maxima against the block's bounds held in SGPRs:
-    //     touch  <=>  lo_b - m <= pmax + delta  and  hi_b + m >= pmin - delta        (per axis)
-    // with delta the rounding of tn, tf and the two end points (a few ulps of |o| + tf |d|: below 1e-6 of the distances m is
-    // proportional to with a factor >= 2^-8), covered by using m for it: pming = pmin - 2m, pmaxg = pmax + 2m.  For the flat layer of
-    // small spheres of the reference's scenes the segment is short (the ray crosses the layer), so the bounds are as tight as the slab
-    // test; a ray running along the layer gets loose bounds -- conservative, never wrong.  A ray that misses the small class's box
-    // touches no block of it; a ray that does not use the filter (not ok) touches every block; the BIG class's blocks carry infinite
-    // bounds (never skipped); lanes without a ray are masked out of the vote.
-    [[maybe_unused]] unsigned bin_lo[3] = {0, 0, 0}, bin_hi[3] = {0, 0, 0};     // the bins of the ray's bounds
-#if RTW_CULL_SPLIT
-    [[maybe_unused]] unsigned bin_lo2[3] = {0, 0, 0}, bin_hi2[3] = {0, 0, 0};   // (second half of the clipped segment)
-#endif
-    [[maybe_unused]] bool cells_ok = false;                                       // the ray uses the filter and meets the small class's box
-    [[maybe_unused]] unsigned flag_word = 0;                                      // which word behind a group's tables the ray ORs in: BIG / live / 0
-    if constexpr (CULLED) {
-        const float ex = ox - mc->cs[0], ey = oy - mc->cs[1], ez = oz - mc->cs[2];
-        const float eps_p = (s2 > 1.0f ? s2 - 1.0f : 0.0f) + 2.4e-7f * s2;
-        // (hardware approximations v_sqrt_f32 / v_rcp_f32, 1 ulp: m is inflated by 2^-10 for them, and the reciprocals only place the end
-        //  points of the clip, whose rounding the 2 m of slack covers a thousandfold -- the IEEE forms cost 65 instructions per scan)
-        const float m = 1.001f * (0.00390625f * (s2 > 1.0f ? s2 : 1.0f) + 2.0f * __builtin_amdgcn_sqrtf(eps_p)) *
-                        ((__builtin_amdgcn_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) + mc->rs) + 1.0f);
-        // 1 / d_k with |d_k| clamped to >= 1e-9 (moves the ray by < 1e-9 t): max on the magnitude, the sign copied back (v_max_f32 |x|, v_bfi_b32, v_rcp_f32)
-        auto safe_inv = [](float x) {
-            const float mag = __builtin_fmaxf(__builtin_fabsf(x), 1e-9f);
-            return __builtin_amdgcn_rcpf(__uint_as_float((__float_as_uint(mag) & 0x7fffffffu) | (__float_as_uint(x) & 0x80000000u)));
-        };
-        const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
-        const float x0 = ((mc->glo[0] - m) - ox) * ix, x1 = ((mc->ghi[0] + m) - ox) * ix;
-        const float y0 = ((mc->glo[1] - m) - oy) * iy, y1 = ((mc->ghi[1] + m) - oy) * iy;
-        const float z0 = ((mc->glo[2] - m) - oz) * iz, z1 = ((mc->ghi[2] + m) - oz) * iz;
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1)), 0.0f);
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-        const float m2 = m + m;
-        const float ax = __builtin_fmaf(tn, dx, ox), ay = __builtin_fmaf(tn, dy, oy), az = __builtin_fmaf(tn, dz, oz);
-        const float bx = __builtin_fmaf(tf, dx, ox), by = __builtin_fmaf(tf, dy, oy), bz = __builtin_fmaf(tf, dz, oz);
-        // (for a ray that uses the filter every quantity above is finite: |o_k| <= mf_o_max, |d|^2 <= 1.0009, |1 / d_k| <= 1e9; the others are
-        //  handled by the mask below, whatever their bounds came out as)
-        const bool hits_class = tf >= tn;
-        const float lo3[3] = {__builtin_fminf(ax, bx) - m2, __builtin_fminf(ay, by) - m2, __builtin_fminf(az, bz) - m2};
-        const float hi3[3] = {__builtin_fmaxf(ax, bx) + m2, __builtin_fmaxf(ay, by) + m2, __builtin_fmaxf(az, bz) + m2};
-        // the bins of the bounds on each axis (inv >= 0); a ray that misses the small class's box is in no block's set (the BIG class comes
-        // in through its flag word), one that does not use the filter takes every live block
-        const CullGrid &G = mc->grid;
-        auto binf = [](float u) { return (unsigned)__builtin_amdgcn_fmed3f(u, 0.0f, (float)RTW_CULL_BINS - 0.5f); };       // (NaN -> 0)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            bin_lo[k] = binf(__builtin_fmaf(lo3[k], G.inv[k], G.off[k]));
-            bin_hi[k] = binf(__builtin_fmaf(hi3[k], G.inv[k], G.off[k]));
-        }
-#if RTW_CULL_SPLIT
-        {   // the two halves of the segment, each with its own bounds: [a, mid] and [mid, b]
-            const float tm = 0.5f * (tn + tf);
-            const float mid[3] = {__builtin_fmaf(tm, dx, ox), __builtin_fmaf(tm, dy, oy), __builtin_fmaf(tm, dz, oz)};
-            const float pa3[3] = {ax, ay, az}, pb3[3] = {bx, by, bz};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                bin_lo[k] = binf(__builtin_fmaf(__builtin_fminf(pa3[k], mid[k]) - m2, G.inv[k], G.off[k]));
-                bin_hi[k] = binf(__builtin_fmaf(__builtin_fmaxf(pa3[k], mid[k]) + m2, G.inv[k], G.off[k]));
-                bin_lo2[k] = binf(__builtin_fmaf(__builtin_fminf(pb3[k], mid[k]) - m2, G.inv[k], G.off[k]));
-                bin_hi2[k] = binf(__builtin_fmaf(__builtin_fmaxf(pb3[k], mid[k]) + m2, G.inv[k], G.off[k]));
-            }
-        }
-#endif
-        cells_ok = ok && hits_class;
-        flag_word = 6u * RTW_CULL_BINS + (has_ray ? (ok ? 0u : 1u) : 2u);
-    }
-    uint4 A1 = {0u, 0u, 0u, 0u}, A2 = {0u, 0u, 0u, 0u};
-    if constexpr (!CULLED) { A1 = pa[0]; A2 = pa[64]; }
     // Wave priority: low inside the block loop, raised for everything else (pass 2 and the divergent phases of the lane loop are
     // chains of dependent LDS / VALU instructions; a wave in the block loop issues a 32-cycle MFMA pair and waits for it
     // anyway).  Measured at Float32: 372.1 -> 368.0 ms on one box, 361.8 -> 359.9 on a faster one, group cull 345.6 -> 343.0; which of
@@ -1078,21 +1081,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     [[maybe_unused]] unsigned vote0 = 0, vote1 = 0, todo = 0;
     int blk = base;
     if constexpr (CULLED) {
-        const unsigned *t = mc->tab + (base >> 5) * RTW_CULL_TAB_WORDS;
-        unsigned mine = (t[0 * RTW_CULL_BINS + bin_hi[0]] & t[1 * RTW_CULL_BINS + bin_lo[0]]) & (t[2 * RTW_CULL_BINS + bin_hi[1]] & t[3 * RTW_CULL_BINS + bin_lo[1]]) &
-                        (t[4 * RTW_CULL_BINS + bin_hi[2]] & t[5 * RTW_CULL_BINS + bin_lo[2]]);
-#if RTW_CULL_SPLIT
-        mine |= (t[0 * RTW_CULL_BINS + bin_hi2[0]] & t[1 * RTW_CULL_BINS + bin_lo2[0]]) & (t[2 * RTW_CULL_BINS + bin_hi2[1]] & t[3 * RTW_CULL_BINS + bin_lo2[1]]) &
-                (t[4 * RTW_CULL_BINS + bin_hi2[2]] & t[5 * RTW_CULL_BINS + bin_lo2[2]]);
-#endif
-        mine = (cells_ok ? mine : 0u) | t[flag_word];
-        // OR over the 16 lanes of a row (xor butterfly on the DPP network), then the two rows of each half wave
-        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
-        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
-        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x141, 0xf, 0xf, true);    // row_half_mirror
-        mine |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x140, 0xf, 0xf, true);    // row_mirror
-        vote0 = (unsigned)__builtin_amdgcn_readlane((int)mine, 0) | (unsigned)__builtin_amdgcn_readlane((int)mine, 16);
-        vote1 = (unsigned)__builtin_amdgcn_readlane((int)mine, 32) | (unsigned)__builtin_amdgcn_readlane((int)mine, 48);
+        block_sets(base, vote0, vote1);
         todo = vote0 | vote1;
         clk.count(7, (unsigned)(n_blocks - base < 32 ? n_blocks - base : 32));
         clk.count(6, (unsigned)((n_blocks - base < 32 ? n_blocks - base : 32) - __popc(todo)));
