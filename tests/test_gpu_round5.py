@@ -102,17 +102,25 @@ def _vote_scenes(T):
 
 
 @pytest.mark.parametrize("T", [np.float32, np.float64])
-def test_block_vote_never_skips_a_block_a_ray_can_hit(oracle, T):
+def test_block_vote_never_skips_a_block_a_ray_can_hit(oracle, rtw, T):
     """group cull (flags 1: table vote on the matrix pipe) == plain scan == oracle on scenes built against the vote: block sets of two
     groups, boxes ending on bin edges, a flat class, mostly empty bins, concentric spheres; wide and narrow cameras"""
     g0 = load_golden("cfg1_2spheres_96x54_16spp_d4_f32")
     cam_wide = {k: np.asarray(v).astype(T) for k, v in g0["cam"].items()}
-    for name, flat in _vote_scenes(T).items():
-        g = dict(g0, flat=flat, cam=cam_wide, image=np.zeros((1, 1, 3), T))
+    scenes = {k: (v, cam_wide) for k, v in _vote_scenes(T).items()}
+    # a class far from the origin (the bin offset -glo * inv is then rounded by whole fractions of a bin: host and device must agree on it)
+    rng = np.random.default_rng(29)
+    n, off = 500, np.array([2000.0, -1000.0, 3000.0])
+    far = _flat_scene(T, off[0] + rng.uniform(-6, 6, n), off[1] + rng.uniform(-0.3, 0.3, n), off[2] + rng.uniform(-6, 6, n), rng.uniform(0.1, 0.3, n), 6)
+    cam = rtw.default_camera(tuple(off + [0.5, 2.0, 14.0]), tuple(off), (0, 1, 0), 50, 16 / 9, 0.0, 14.0, elem_type=T)
+    scenes["far_from_origin"] = (far, {k: getattr(cam, k) for k in oracle.CAM_FIELDS + ("lens_radius",)})
+    for name, (flat, cam_d) in scenes.items():
+        g = dict(g0, flat=flat, cam=cam_d, image=np.zeros((1, 1, 3), T))
         ref, ost = oracle.render(flat, g["cam"], 96, 54, 4, T=T, max_depth=12, seed=5, n_chunks=2)
         for flags in (1, 0, 5):
             img, st = gpu_render(g, width=96, height=54, spp=4, n_chunks=2, max_depth=12, seed=5, flags=flags)
             assert np.array_equal(img, ref) and st.segments == ost["segments"], (name, flags)
+        assert np.unique(ref.reshape(-1, 3), axis=0).shape[0] > 50, name       # the spheres are in view
 
 
 # ---- test aids need the master switch ------------------------------------------------------------------------------------------
