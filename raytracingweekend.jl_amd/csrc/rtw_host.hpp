@@ -51,7 +51,7 @@ struct rtw_scene_dev {
     float c_glo[3], c_ghi[3];   // the box of the whole small class (union of the block boxes): the ray is clipped against it once per scan
     int c_mf_blocks;
     float c_grid[6];       // the bins of the per-ray block vote (rtw::CullGrid: inv[3], off[3]); its tables lie behind the boxes in c_mf_box
-    int c_huge[2];         // the huge spheres' indices in the cluster-major order (n_huge of them)
+    int c_n_inlane, c_inlane[8];   // spheres of the cluster-major order that every lane tests by itself (rtw::RTW_CULL_INLANE_MAX): the huge spheres and, when it fits, the whole BIG class
     // opt-in group-cull mode (RTW_FLAG_GROUP_CULL): cluster-major copies
     void *c_bound, *c_exact, *c_mat0, *c_mat1;
     unsigned short *c_orig;

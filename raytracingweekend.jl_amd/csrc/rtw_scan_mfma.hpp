@@ -81,13 +81,15 @@ typedef float rtw_f16v __attribute__((ext_vector_type(16)));
 // bounds can overlap -- a superset of the exact box test by at most one bin width per side.  The sets of a half wave are ORed on the DPP
 // network (4 steps): that is the whole vote, once per scan and group of 32 blocks, instead of 10 VALU instructions per (scan, block).
 // Tables (uint32, behind the boxes: box + 8 (blocks + 1)), per group of 32 blocks RTW_CULL_TAB_WORDS words:
-//     [axis][0: lo_b <= edge, indexed by the bin of hi | 1: hi_b >= edge, indexed by the bin of lo][bin], then {BIG blocks, live blocks, 0, 0}
+//     [axis][0: lo_b <= edge, indexed by the bin of hi | 1: hi_b >= edge, indexed by the bin of lo][bin], then {BIG blocks, live blocks, 0, 0},
+//     then RTW_CULL_INLANE_MAX sphere indices (first group: the in-lane list, MfmaCull::n_huge of them)
 // (BIG: touched by every ray; live: what a ray without the filter touches; dead blocks are in no set).
 // 64 bins: one table = 64 words = one word per LDS bank, any 64 look-ups are conflict-free; 128 bins measured 8 % SLOWER (317 vs 293 ms).
 #ifndef RTW_CULL_BINS
 #define RTW_CULL_BINS 64
 #endif
-#define RTW_CULL_TAB_WORDS (6 * RTW_CULL_BINS + 4)
+#define RTW_CULL_INLANE_MAX 8
+#define RTW_CULL_TAB_WORDS (6 * RTW_CULL_BINS + 4 + RTW_CULL_INLANE_MAX)
 __host__ __device__ inline int cull_tab_words(int blocks) { return ((blocks + 31) / 32 > 0 ? (blocks + 31) / 32 : 1) * RTW_CULL_TAB_WORDS; }
 struct CullGrid {
     float inv[3], off[3];          // bin of a coordinate p on axis k: floor(p inv[k] + off[k]) clamped to 0 .. RTW_CULL_BINS - 1
@@ -100,7 +102,7 @@ struct MfmaCull {
     float cs[3], rs;      // bounding sphere of the small class (the margin grows with the distance to it)
     const void *mat0;     // the cold rows in this (device) order: mat0[i].x = the radius (NUM_REFERENCE_FMA2)
     float glo[3], ghi[3]; // the box of the whole small class (the union of its blocks' boxes): a ray is clipped against it ONCE per scan
-    int n_huge, huge[2];  // huge spheres (device order), tested in-lane like DevScene::huge
+    int n_huge;           // spheres (device order) tested in-lane like DevScene::huge -- the huge ones and, when it fits, the whole BIG class: their indices follow the flag words of the first group's tables
     CullGrid grid;        // the block vote: bins ...
     const unsigned *tab;  // ... and tables (global memory, or the workgroup's copy in LDS)
 };
@@ -404,7 +406,9 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         using V4 = typename Vec4<T>::type;
         const int n_huge = CULLED ? mc->n_huge : w.n_huge;
         for (int hgi = 0; hgi < n_huge; ++hgi) {
-            const int si = CULLED ? (hgi == 0 ? mc->huge[0] : mc->huge[1]) : (hgi == 0 ? w.huge[0] : w.huge[1]);      // (no dynamic indexing of a by-value struct: that would live in scratch)
+            int si;
+            if constexpr (CULLED) si = __builtin_amdgcn_readfirstlane((int)mc->tab[6 * RTW_CULL_BINS + 4 + hgi]);      // (the list lies with the vote's tables)
+            else si = hgi == 0 ? w.huge[0] : w.huge[1];                  // (no dynamic indexing of a by-value struct: that would live in scratch)
             const V4 sg = src[si];
             T hb_, disc_, root_ = 0;
             T rr_ = T(0);

@@ -16,7 +16,8 @@ rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
     C.kappa = sizeof(T) == 4 ? (T)0.00390625 : (T)2.384185791015625e-07;     // 2^-8 / 2^-22
     C.mf_ops = (const uint4 *)h->c_mf_ops; C.mf_box = (const float *)h->c_mf_box; C.mf_blocks = h->c_mf_blocks;
     for (int k = 0; k < 3; ++k) { C.mf_glo[k] = h->c_glo[k]; C.mf_ghi[k] = h->c_ghi[k]; }
-    C.n_huge = h->c_mf_ops ? h->n_huge : 0; C.huge[0] = h->c_huge[0]; C.huge[1] = h->c_huge[1];
+    static_assert(RTW_CULL_INLANE_MAX == 8, "rtw_scene_dev::c_inlane");
+    C.n_huge = h->c_mf_ops ? h->c_n_inlane : 0;
     for (int k = 0; k < 3; ++k) { C.grid.inv[k] = h->c_grid[k]; C.grid.off[k] = h->c_grid[3 + k]; }
     C.numerics = rtw::NUM_REFERENCE;
     return C;

@@ -95,6 +95,14 @@ def _vote_scenes(T):
     cx = np.r_[rng.uniform(-60, -58, n), rng.uniform(58, 60, n), [0.0, 3.0, -3.0]]
     cz = np.r_[rng.uniform(-40, -38, n), rng.uniform(-12, -10, n), [-8.0, -8.0, -8.0]]
     out["two_clumps"] = _flat_scene(T, cx, np.r_[rng.uniform(-1, 1, 2 * n), [0.0, 0.0, 0.0]], cz, np.r_[rng.uniform(0.1, 0.4, 2 * n), [1.5, 1.0, 1.0]], 4)
+    # the BIG class (|r| > 4 x the median radius) in Float32: up to 8 of its spheres are tested by every lane itself and its block is dead;
+    # 9 stay a block that every half wave visits; a huge ground sphere (>= 16 x the median) is in the list either way
+    n = 160
+    for nbig in (7, 8, 9, 40):
+        cx = np.r_[rng.uniform(-8, 8, n), np.linspace(-7, 7, nbig), 0.0]
+        cz = np.r_[rng.uniform(-14, -3, n), rng.uniform(-12, -5, nbig), -8.0]
+        cy = np.r_[rng.uniform(-0.2, 0.2, n), np.full(nbig, 0.9), -400.0]
+        out[f"big_class_{nbig}_plus_ground"] = _flat_scene(T, cx, cy, cz, np.r_[rng.uniform(0.08, 0.2, n), rng.uniform(0.8, 1.1, nbig), 399.0], 40 + nbig)
     # all spheres concentric (zero extent of the centres; boxes differ by the radii only)
     n = 40
     out["concentric"] = _flat_scene(T, np.zeros(n), np.zeros(n), np.full(n, -6.0), np.linspace(0.5, 2.5, n), 5)
