@@ -36,7 +36,7 @@ end
 CCamera(c::Camera{T}) where T = CCamera{T}(Tuple(c.origin), Tuple(c.lower_left_corner), Tuple(c.horizontal),
                                            Tuple(c.vertical), Tuple(c.u), Tuple(c.v), Tuple(c.w), c.lens_radius)
 
-# rtw_params (ABI version 2)
+# rtw_params (ABI version 3: same layout as version 2; new flag bits)
 struct CParams
     width::Int32; height::Int32; spp::Int32; max_depth::Int32
     seed::UInt64
