@@ -61,7 +61,8 @@ typedef struct {
 
 /* rtw_params.flags.  RTW_FLAG_GROUP_CULL: opt-in accelerated closest-hit scan:
  * spheres are clustered at upload (kd clusters with boxes) and spheres that a ray provably cannot hit are never
- * tested: a block of 32 spatially sorted spheres is skipped when no ray of the wave can touch its box (default),
+ * tested: a block of 32 spatially sorted spheres is visited only when some ray of the half wave can touch its box
+ * (default: per-ray block sets looked up from tables, ORed over the half wave),
  * or, with RTW_FLAG_SCAN_VALU, per ray and cluster of 16 on the vector ALUs (the round-1/2 form).
  * Bit-identical images; default (0) is the reference's plain linear scan. */
 #define RTW_FLAG_GROUP_CULL 1
