@@ -2,6 +2,7 @@
 // (part of the device side of the hot path, gfx950 only; see rtw_device.hpp for the numerics contract all parts share)
 #pragma once
 #include "rtw_scan.hpp"
+#include "rtw_cull_tables.hpp"
 
 namespace rtw {
 
@@ -85,11 +86,7 @@ typedef float rtw_f16v __attribute__((ext_vector_type(16)));
 //     then RTW_CULL_INLANE_MAX sphere indices (first group: the in-lane list, MfmaCull::n_huge of them)
 // (BIG: touched by every ray; live: what a ray without the filter touches; dead blocks are in no set).
 // 64 bins: one table = 64 words = one word per LDS bank, any 64 look-ups are conflict-free; 128 bins measured 8 % SLOWER (317 vs 293 ms).
-#ifndef RTW_CULL_BINS
-#define RTW_CULL_BINS 64
-#endif
-#define RTW_CULL_INLANE_MAX 8
-#define RTW_CULL_TAB_WORDS (6 * RTW_CULL_BINS + 4 + RTW_CULL_INLANE_MAX)
+// (RTW_CULL_BINS, RTW_CULL_INLANE_MAX, RTW_CULL_TAB_WORDS: rtw_cull_tables.hpp, with the host code that builds the tables)
 __host__ __device__ inline int cull_tab_words(int blocks) { return ((blocks + 31) / 32 > 0 ? (blocks + 31) / 32 : 1) * RTW_CULL_TAB_WORDS; }
 struct CullGrid {
     float inv[3], off[3];          // bin of a coordinate p on axis k: floor(p inv[k] + off[k]) clamped to 0 .. RTW_CULL_BINS - 1

@@ -2,6 +2,7 @@
 // kernels read, the kd split and boxes of the opt-in group-cull layout, and the sphere-side operands of the matrix-pipe filter
 // (hit_world_mfma, rtw_device.hpp) with their error-margin constants.  Host code only; -ffp-contract=off like the kernels.
 #include "rtw_scene_view.hpp"
+#include "rtw_cull_tables.hpp"
 
 namespace rtwh {
 
@@ -183,40 +184,12 @@ int build_cull(const SceneT *s, rtw_scene_dev *h) {
             if (!std::isfinite(q[0]) || q[0] >= 1e15f) continue;                                   // BIG class / nothing alive
             for (int a = 0; a < 3; ++a) { h->c_glo[a] = std::min(h->c_glo[a], q[a]); h->c_ghi[a] = std::max(h->c_ghi[a], q[4 + a]); }
         }
-        // The tables of the block vote (rtw::CullGrid, rtw_device.hpp): RTW_CULL_BINS bins per axis over that box; per group of 32 blocks and
-        // axis the set of blocks with lo_b <= upper edge of the bin / hi_b >= lower edge of the bin.  The edges are moved outwards by 1e-3 of a
-        // bin: the device's binary32 evaluation of p inv + off is off by < 1e-4 of a bin for coordinates inside the box, and the outer bins
-        // reach to infinity.  Dead blocks are in no set.
-        const int n_grp = (nb + 31) / 32;
-        std::vector<float> cells((size_t)std::max(n_grp, 1) * RTW_CULL_TAB_WORDS, 0.0f);
-        {
-            std::vector<unsigned> tab((size_t)std::max(n_grp, 1) * RTW_CULL_TAB_WORDS, 0u);
-            for (int k = 0; k < 3; ++k) {
-                const double ext = h->c_ghi[k] > h->c_glo[k] ? (double)h->c_ghi[k] - (double)h->c_glo[k] : 0.0;
-                const double inv = (double)(float)(ext > 0.0 ? RTW_CULL_BINS / ext : 0.0);            // (a flat or empty class: everything in bin 0)
-                const double off = (double)(float)(ext > 0.0 ? -(double)h->c_glo[k] * inv : 0.0);
-                h->c_grid[k] = (float)inv; h->c_grid[3 + k] = (float)off;
-                for (int j = 0; j < RTW_CULL_BINS; ++j) {
-                    const double edge_hi = (j == RTW_CULL_BINS - 1 || inv == 0.0) ? INFINITY : ((double)(j + 1) + 1e-3 - off) / inv;
-                    const double edge_lo = (j == 0 || inv == 0.0) ? -INFINITY : ((double)j - 1e-3 - off) / inv;
-                    for (int b = 0; b < nb; ++b) {
-                        const float *q = &bx[(size_t)b * 8];
-                        if (std::isfinite(q[0]) && q[0] >= 1e15f) continue;                                // nothing alive
-                        unsigned *t = &tab[(size_t)(b / 32) * RTW_CULL_TAB_WORDS];
-                        if ((double)q[k] <= edge_hi) t[(k * 2 + 0) * RTW_CULL_BINS + j] |= 1u << (b % 32);
-                        if ((double)q[4 + k] >= edge_lo) t[(k * 2 + 1) * RTW_CULL_BINS + j] |= 1u << (b % 32);
-                    }
-                }
-            }
-            for (int b = 0; b < nb; ++b) {
-                const float *q = &bx[(size_t)b * 8];
-                unsigned *t = &tab[(size_t)(b / 32) * RTW_CULL_TAB_WORDS + 6 * RTW_CULL_BINS];
-                if (!std::isfinite(q[0])) { t[0] |= 1u << (b % 32); t[1] |= 1u << (b % 32); }
-                else if (q[0] < 1e15f) t[1] |= 1u << (b % 32);
-            }
-            for (int k = 0; k < h->c_n_inlane; ++k) tab[6 * RTW_CULL_BINS + 4 + k] = (unsigned)h->c_inlane[k];      // the in-lane list (first group's tables)
-            memcpy(cells.data(), tab.data(), tab.size() * sizeof(unsigned));
-        }
+        // The tables of the block vote (rtw::CullGrid): rtw_cull_tables.hpp builds them (plain C++, checked on the CPU by tests/cull_tables_check.cpp)
+        CullTables ct;
+        build_cull_tables(bx.data(), nb, h->c_glo, h->c_ghi, h->c_n_inlane, h->c_inlane, &ct);
+        for (int k = 0; k < 3; ++k) { h->c_grid[k] = ct.inv[k]; h->c_grid[3 + k] = ct.off[k]; }
+        std::vector<float> cells(ct.words.size(), 0.0f);
+        memcpy(cells.data(), ct.words.data(), ct.words.size() * sizeof(unsigned));
         bx.insert(bx.end(), cells.begin(), cells.end());
         HIP_TRY(hipMalloc(&h->c_mf_box, bx.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->c_mf_box, bx.data(), bx.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -250,3 +250,23 @@ def test_c_host_example_compiles_and_links(tmp_path):
     if not _has_gpu():                      # without a device it must fail loudly, not produce pixels
         r = subprocess.run([exe, "64", "1"], capture_output=True, text=True, cwd=str(tmp_path))
         assert r.returncode == 1 and "no HIP device" in r.stderr and not (tmp_path / "render_c.ppm").exists()
+
+
+def test_cull_vote_tables_on_the_cpu(tmp_path):
+    """the group cull's vote tables (csrc/rtw_cull_tables.hpp, plain C++) against the exact box-overlap test they stand for, on the CPU:
+    tests/cull_tables_check.cpp -- random block boxes (lattices on bin edges, flat classes, classes far from the origin, BIG and dead
+    blocks, up to three groups) x random ray bounds: no overlapping block is ever missing from the looked-up set.  The same program built
+    with the bin edges NOT moved outwards (slack 0) must fail: the check can see a rounding-level hole."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cull_tables_check.cpp")
+    ok = str(tmp_path / "ctc_ok")
+    bad = str(tmp_path / "ctc_bad")
+    for exe, extra in ((ok, []), (bad, ["-DRTW_CULL_EDGE_SLACK=0"])):
+        r = subprocess.run(["g++", "-O2", "-std=c++17", *extra, "-o", exe, src], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([ok, "300"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "no block lost" in r.stdout, r.stdout[-500:]
+    ratio = float(r.stdout.split("(")[-1].split(" x")[0])
+    assert 1.0 <= ratio < 1.2, r.stdout                      # a superset, and a tight one
+    r = subprocess.run([bad, "300"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and "not in the set" in r.stdout, r.stdout[-500:]
