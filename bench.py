@@ -39,7 +39,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   value        -- device-resident rate (scene in HBM, image left in HBM), as the task's bench contract prescribes;
                   `value_end_to_end` is SURVEY 8(d)'s metric: the host-buffer entry point rtw_render_* timed the same way (barrier +
                   synchronize around K calls; render + D2H of the image into the caller's buffer; scene upload cached by the library).
-  ray_pool     -- the same workload with RTW_FLAG_RAY_POOL (the ray-pool kernel, rtw_pool.hpp): same image, slower; reported as measured.
+  ray_pool     -- null since round 6: the ray-pool kernel (rtw_pool.hpp; same image, 16 - 19 % slower) is a `make POOL=1` build option.
   scan_valu    -- the same workload with RTW_FLAG_SCAN_VALU (the contract discriminant for every
                   sphere on the vector ALUs, the round-1/2 scan): same image, for comparison.
   cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
@@ -108,15 +108,17 @@ def parse_args(argv=None):
     ap.add_argument("--ray-pool", action="store_true", help="time the opt-in ray-pool kernel (RTW_FLAG_RAY_POOL) instead of the lane-loop kernel")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes that measure roofline.traffic / issue_busy in this run")
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per pixel (0 = library default rule)")
-    ap.add_argument("--numerics", choices=["reference", "contract", "reference_fma", "reference_fma2"], default="reference",
+    ap.add_argument("--numerics", choices=["reference", "contract", "reference_fma2"], default="reference",
                     help="the deciding arithmetic of the ray-sphere test (include/rtw_hip.h RTW_FLAG_NUMERICS_*): reference = src/hit.jl:16-18 as the reference "
                          "evaluates it (the default of the library); the default run also times the other two as `numerics_legs`")
     ap.add_argument("--in-library-devices", type=int, default=0, metavar="N",
                     help="time ONLY the in-library device list (what a Julia caller gets with devices=...): rtw_render_* on host buffers with N devices, "
                          "gathered by peer copies and by the in-library RCCL reduce; N > the visible devices: ordinals repeat (emulation, labelled so)")
+    ap.add_argument("--small-frames", type=int, default=0, metavar="CALLS",
+                    help="time ONLY the small-frame workloads (BASELINE configs[0], configs[1] and the reference's published small renders), CALLS calls each")
     ap.add_argument("--emulate-shard-of", type=int, default=0,
                     help="analysis only: on ONE GPU render shard 0 of N (what each rank of an N-GPU run does)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration per leg")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU-baseline sample duration per leg (a leg per thread count: 16, 32, 64, all)")
     ap.add_argument("--collective", choices=["reduce", "gather"], default="reduce",
                     help="N > 1: reduce = sum of zero-padded full frames onto rank 0 (BASELINE configs[3]); "
                          "gather = each rank sends only its compact tile-major shard (1/N of a frame)")
@@ -419,30 +421,169 @@ def live_pmc(dtype, width, spp, depth, numerics="reference", timeout_s=90):
         shutil.rmtree(base, ignore_errors=True)
 
 
-def cpu_legs(wl, seconds):
-    """The CPU oracle on this box's host cores, bounded sample: [16-thread leg (if the box has 16), all-threads leg]."""
-    import rtw_oracle as O
-    O.build()
-    R = wl.c.R
-    flat = R.flatten_scene(wl.scene, wl.T)
-    threads = O.max_threads()
+def host_cpu_info():
+    """what this process may use of the host: affinity mask, cgroup CPU quota, logical CPUs"""
+    info = {"logical_cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cgroup_cpu_max": None}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            info["cgroup_cpu_max"] = open(path).read().strip()
+            break
+        except OSError:
+            pass
+    try:
+        info["model"] = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
+    except Exception:
+        info["model"] = None
+    return info
 
-    def leg(nthr):
-        t = time.perf_counter()
-        O.render(flat, wl.cam, wl.W, wl.H, 1, T=wl.T, max_depth=wl.depth, seed=1, n_chunks=1, omp_threads=nthr, numerics=wl.c.args.numerics)
-        t1 = time.perf_counter() - t
-        s_spp = int(max(1, min(64, round(seconds / max(t1, 1e-3)))))
-        t = time.perf_counter()
-        O.render(flat, wl.cam, wl.W, wl.H, s_spp, T=wl.T, max_depth=wl.depth, seed=1, omp_threads=nthr, numerics=wl.c.args.numerics)
-        tc = time.perf_counter() - t
-        return {"value": round(wl.W * wl.H * s_spp / tc / 1e6, 4), "unit": "Msamples/s", "cores": nthr, "kind": "port",
-                "sample": f"same scene/camera/{wl.W}x{wl.H}/depth {wl.depth}/{wl.jl}, {s_spp} spp ({tc:.1f} s), oracle/ C port with OpenMP; "
-                          f"the Julia reference cannot run here (no julia in the image)"}
-    # the GPU boxes are shared hosts (2 x EPYC 9575F, cgroup-limited): all-threads runs are often SLOWER than
-    # 16 threads there.  Both legs are reported; `cpu_baseline` is the faster one (the fairer baseline).
-    legs = [leg(16)] if threads >= 16 else []
-    legs.append(leg(threads))
-    return legs, (legs[0] if threads >= 16 else None)
+
+def cpu_leg_child(argv):
+    """`bench.py --cpu-leg dtype width depth numerics threads seconds`: ONE timing of the CPU oracle in a fresh process whose OpenMP runtime was
+    started with the binding of the environment (OMP_PLACES / OMP_PROC_BIND are read when libgomp initialises: not changeable in the parent,
+    where torch has loaded it long ago).  No torch, no GPU.  Prints one JSON line."""
+    import numpy as np
+    import rtw_amd as R
+    import rtw_oracle as O
+    dtype, W, depth, numerics, nthr, seconds = argv[0], int(argv[1]), int(argv[2]), argv[3], int(argv[4]), float(argv[5])
+    O.build()
+    T = np.float64 if dtype == "f64" else np.float32
+    H = R.image_height(W)
+    R.reseed()
+    scene, cam = R.scene_random_spheres(elem_type=T), R.t_cam1(elem_type=T)
+    flat = R.flatten_scene(scene, T)
+    t = time.perf_counter()
+    O.render(flat, cam, W, H, 1, T=T, max_depth=depth, seed=1, n_chunks=1, omp_threads=nthr, numerics=numerics)
+    t1 = time.perf_counter() - t
+    s_spp = int(max(1, min(64, round(seconds / max(t1, 1e-3)))))
+    t = time.perf_counter()
+    O.render(flat, cam, W, H, s_spp, T=T, max_depth=depth, seed=1, omp_threads=nthr, numerics=numerics)
+    tc = time.perf_counter() - t
+    print(json.dumps({"value": round(W * H * s_spp / tc / 1e6, 4), "spp": s_spp, "seconds": round(tc, 2), "threads": nthr}), flush=True)
+
+
+def cpu_legs(wl, seconds, thread_counts=None):
+    """The CPU oracle (kind "port"; the Julia reference cannot run here) on this box's host cores, bounded sample, as a CURVE over thread
+    counts -- 16 (the north star's comparison point), 32, 64 and every CPU this process may use -- each leg in its own process with the
+    threads pinned (OMP_PLACES=cores OMP_PROC_BIND=close, passive waiting).  Returns (legs, the 16-thread leg or None)."""
+    host = host_cpu_info()
+    avail = host["affinity_cpus"] or host["logical_cpus"] or 1
+    counts = thread_counts or sorted({n for n in (16, 32, 64, avail) if n <= avail} or {avail})
+    legs = []
+    for nthr in counts:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(OMP_NUM_THREADS=str(nthr), OMP_PLACES="cores", OMP_PROC_BIND="close", OMP_WAIT_POLICY="passive", OMP_DYNAMIC="false")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", wl.dtype, str(wl.W), str(wl.depth), wl.c.args.numerics, str(nthr), str(seconds)]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=max(120.0, 12 * seconds))
+            d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:
+            legs.append({"value": 0.0, "unit": "Msamples/s", "cores": nthr, "kind": "port", "sample": f"FAILED: {str(e)[:200]}"})
+            continue
+        legs.append({"value": d["value"], "unit": "Msamples/s", "cores": nthr, "kind": "port",
+                     "sample": f"same scene/camera/{wl.W}x{wl.H}/depth {wl.depth}/{wl.jl}, {d['spp']} spp ({d['seconds']:.1f} s), oracle/ C port, OpenMP schedule(dynamic, 64) over "
+                               f"pixels, {nthr} threads pinned (OMP_PLACES=cores OMP_PROC_BIND=close, own process); the Julia reference cannot run here (no julia in the image)"})
+    curve = {str(l["cores"]): l["value"] for l in legs}
+    best = max(legs, key=lambda l: l["value"])
+    for l in legs:
+        l["thread_curve_Msamples_per_s"] = curve
+        l["host"] = host
+    if len(legs) > 1 and legs[-1]["value"] < 0.9 * best["value"]:
+        best["sample"] += (f"; more threads are SLOWER here ({curve}): the process may use {avail} logical CPUs (cgroup cpu.max: {host['cgroup_cpu_max']}) of a shared host -- "
+                           "beyond the physical cores it is granted the pinned threads share cores (SMT siblings / CFS quota throttling), and the path is latency-bound scalar code")
+    return legs, next((l for l in legs if l["cores"] == 16), None)
+
+
+SMALL_FRAMES = [
+    # (key, scene builder, camera, width, spp, depth, dtype, what, published ms on the reference's Ryzen 3700 / 16 threads or None)
+    ("cfg1_random_320x180_64spp_d16_f32", "scene_random_spheres", "t_cam1", 320, 64, 16, "f32",
+     "BASELINE.json configs[1]: scene_random_spheres, 320x180, 64 spp, depth 16, Float32", None),
+    ("proto_random_200x112_32spp_d16_f64", "scene_random_spheres", "t_cam1", 200, 32, 16, "f64",
+     "render(scene_random_spheres, t_cam1, 200, 32), Float64, depth 16 (/root/reference/src/proto/proto.jl:195-200: 296.824 ms)", 296.824),
+    ("proto_2spheres_96x54_16spp_d16_f64", "scene_2_spheres", "t_default_cam", 96, 16, 16, "f64",
+     "render(scene_2_spheres, t_default_cam, 96, 16), Float64, depth 16 (/root/reference/src/proto/proto.jl:64-66: 951.447 us)", 0.951447),
+    ("cfg0_2spheres_96x54_16spp_d4_f32", "scene_2_spheres", "t_default_cam", 96, 16, 4, "f32",
+     "BASELINE.json configs[0]: scene_2_spheres, 96x54, 16 spp, depth 4, Float32 (the reference's CPU-runnable case)", None),
+]
+
+
+def small_frames_leg(c, headline_rate, calls=200, cull_too=True):
+    """The launch- / tail-bound regime: BASELINE configs[1] and the small workloads the reference itself publishes.
+    Per workload, the C entry points are called DIRECTLY (prebuilt ctypes structs: what a `ccall` costs, no Python scene flattening in
+    the timed region):
+      host   rtw_render_* on host buffers (scene cached by the library; render + D2H into the caller's buffer; blocking), `calls` calls,
+             each timed by itself with perf_counter_ns -> median / min / p90 in us, kernel us (HIP events of the same calls, median),
+             overhead = median call - median kernel;
+      device rtw_render_device_* into a device buffer + stream synchronize (the device-resident rate, like `value`)."""
+    import ctypes as C
+    import statistics
+    np, torch, R = c.np, c.torch, c.R
+    from rtw_amd import _capi
+    L = _capi.lib()
+    out = {"calls": calls, "headline_Msamples_per_s": round(headline_rate, 2),
+           "how": "direct C-ABI calls with prebuilt structs; per-call perf_counter_ns; kernel = HIP events around the launch (rtw_stats)"}
+    for key, scene_fn, cam_fn, W, spp, depth, dtype, what, pub_ms in SMALL_FRAMES:
+        T = np.float64 if dtype == "f64" else np.float32
+        R.reseed()
+        scene = getattr(R, scene_fn)(elem_type=T)
+        cam = getattr(R, cam_fn)(elem_type=T)
+        H = R.image_height(W)
+        flat = R.flatten_scene(scene, T)
+        S, keep = _capi.make_scene(flat, T)
+        Cm = _capi.make_camera(cam, T)
+        host = np.empty(H * W * 3, dtype=T)
+        fn = L.rtw_render_f64 if dtype == "f64" else L.rtw_render_f32
+        fnd = L.rtw_render_device_f64 if dtype == "f64" else L.rtw_render_device_f32
+        st = _capi.Stats()
+        samples = W * H * spp
+        entry = {"workload": what, "samples": samples}
+        modes = [("plain", 0)] + ([("group_cull", _capi.FLAG_GROUP_CULL)] if (cull_too and scene_fn == "scene_random_spheres") else [])
+        for mode, flags in modes:
+            P = _capi.make_params(W, H, spp, depth, 1, 0, 0, 1, c.local_rank, 1, flags, numerics=c.args.numerics)
+            outp = host.ctypes.data_as(C.c_void_p)
+            for _ in range(5):
+                _capi.check(fn(C.byref(S), C.byref(Cm), C.byref(P), outp))
+            t_us, k_us = [], []
+            for _ in range(calls):
+                t0 = time.perf_counter_ns()
+                rc = fn(C.byref(S), C.byref(Cm), C.byref(P), outp)
+                t1 = time.perf_counter_ns()
+                _capi.check(rc)
+                _capi.check(L.rtw_stats(C.byref(st)))
+                t_us.append((t1 - t0) / 1e3)
+                k_us.append(st.kernel_ms * 1e3)
+            t_us.sort()
+            med, kmed = statistics.median(t_us), statistics.median(k_us)
+            # device-resident: the scene handle is the caller's, the image stays in HBM
+            handle = C.c_void_p()
+            up = L.rtw_scene_upload_f64 if dtype == "f64" else L.rtw_scene_upload_f32
+            _capi.check(up(C.byref(S), c.local_rank, C.byref(handle)))
+            fb = torch.empty(H * W * 3, dtype=torch.float64 if dtype == "f64" else torch.float32, device=c.dev)
+            Pd = _capi.make_params(W, H, spp, depth, 1, 0, 0, 1, -1, 1, flags, numerics=c.args.numerics)
+            d_us = []
+            for k in range(calls + 5):
+                t0 = time.perf_counter_ns()
+                rc = fnd(handle, C.byref(Cm), C.byref(Pd), C.c_void_p(fb.data_ptr()), C.c_void_p(c.stream.cuda_stream))
+                c.stream.synchronize()
+                t1 = time.perf_counter_ns()
+                _capi.check(rc)
+                if k >= 5:
+                    d_us.append((t1 - t0) / 1e3)
+            L.rtw_scene_free(handle)
+            dmed = statistics.median(d_us)
+            e = {"call_us_median": round(med, 1), "call_us_min": round(t_us[0], 1), "call_us_p90": round(t_us[int(0.9 * (len(t_us) - 1))], 1),
+                 "kernel_us_median": round(kmed, 1), "overhead_us": round(med - kmed, 1),
+                 "Msamples_per_s": round(samples / med, 2), "kernel_only_Msamples_per_s": round(samples / max(kmed, 1e-3), 2),
+                 "device_resident_us_median": round(dmed, 1), "device_resident_Msamples_per_s": round(samples / dmed, 2),
+                 "frac_of_headline": round(samples / med / headline_rate, 4), "grid_blocks": st.grid_blocks, "n_chunks": st.n_chunks,
+                 "segments_per_sample": round(st.segments / max(1, st.samples), 4)}
+            if pub_ms is not None and mode == "plain":
+                e["vs_published"] = {"published_ms": pub_ms, "ratio": round(pub_ms * 1e3 / med, 1),
+                                     "published_on": "Ryzen 3700 (8C/16T), julia -t 16 -- DIFFERENT HARDWARE, context only"}
+            entry[mode] = e
+            fb = None
+        del keep
+        out[key] = entry
+    return out
 
 
 def in_library_leg(c, wl, n_devices, numerics, steps=2):
@@ -500,6 +641,8 @@ def cfg_name(dtype, W, spp, depth, world):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-leg":
+        return cpu_leg_child(sys.argv[2:])
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)                                        # does not return
@@ -507,6 +650,11 @@ def main():
     np, torch, dist, R = c.np, c.torch, c.dist, c.R
     rank, world = c.rank, c.world
 
+    if args.small_frames > 0:                                   # this leg only (tools/gpu_small_frames.sh; profiling passes)
+        if world != 1:
+            raise SystemExit("--small-frames is a one-process mode")
+        print(json.dumps({"small_frames": small_frames_leg(c, 0.0 + float(os.environ.get("RTW_HEADLINE_RATE", "5600")), calls=args.small_frames)}), flush=True)
+        return
     wl = Workload(c, args.dtype, args.width, args.spp, args.depth)
     W, H, spp, depth = wl.W, wl.H, wl.spp, wl.depth
     if args.in_library_devices > 0:                             # this leg only (tools/gpu_multi.sh; one process, the library drives the devices)
@@ -560,15 +708,7 @@ def main():
         scan_valu = {"mode": "RTW_FLAG_SCAN_VALU (the discriminant of the numerics mode for every sphere on the vector ALUs: no filter, no margin constants; same image bit for bit)",
                      "value": round(samples_per_step / dtv / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtv * 1e3, 3), "steps": nv, "warmup": 1,
                      "frame_sha256_equal": (wl.frame_sha256() == sha) if rank == 0 else None}
-    ray_pool = None
-    if extras and not (args.group_cull or args.scan_valu or args.ray_pool) and args.dtype == "f32":
-        stp_ = []
-        np_ = max(1, min(args.steps, 2))
-        dtp_ = wl.timed(np_, 1, cull=False, depth=depth, pool=True, record=stp_) / np_          # (one warm-up: the first launch loads the code object and sets the LDS attribute)
-        ray_pool = {"mode": "RTW_FLAG_RAY_POOL (rays of a workgroup parked in LDS between the stages scan / shade / path end, every stage on full waves of one kind; "
-                            "same image bit for bit; a measured LOSS on this chip, DESIGN.md section 6.4)",
-                    "value": round(samples_per_step / dtp_ / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dtp_ * 1e3, 3), "steps": np_, "warmup": 1,
-                    "block_threads": stp_[0]["block_threads"], "frame_sha256_equal": (wl.frame_sha256() == sha) if rank == 0 else None}
+    ray_pool = None      # (round 6: the ray-pool kernel is a `make POOL=1` build option -- tools/gpu_pool_check.sh times it; `--ray-pool` needs such a build)
     if extras and depth != 16:
         st16 = []
         dt16 = wl.timed(1, 0, cull=args.group_cull, depth=16, record=st16, valu=args.scan_valu)
@@ -578,7 +718,7 @@ def main():
     numerics_legs = in_lib = None
     if extras and not (args.group_cull or args.scan_valu or args.ray_pool):
         numerics_legs = {}
-        for mode in ("reference", "contract", "reference_fma", "reference_fma2"):
+        for mode in ("reference", "contract", "reference_fma2"):
             if mode == args.numerics:
                 continue
             stn = []
@@ -617,7 +757,15 @@ def main():
                       "note": "rtw_render_* on host buffers (SURVEY 8(d)'s definition of the metric): render + D2H of the image, PCIe-inclusive, blocking; "
                               "the scene upload is cached between calls (first_call_ms includes it)"}
 
+    small = None
+    if extras and world == 1 and not (args.group_cull or args.scan_valu or args.ray_pool):
+        try:
+            small = small_frames_leg(c, value)
+        except Exception as e:                                   # (never costs the headline line)
+            small = {"error": str(e)[:300]}
+
     line = None
+    cpu_counts_short = None
     if rank == 0:
         # the only kernel = trace_kernel.  Per launch (this rank's shard): algorithmic flops =
         # sphere tests x 17; duration = mean HIP-event time on the launch stream.
@@ -636,6 +784,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             legs, cpu16 = cpu_legs(wl, args.cpu_seconds)
             cpu = max(legs, key=lambda d: d["value"])
+            cpu_counts_short = sorted({cpu["cores"]} | ({16} if cpu16 else set()))       # the Float64 legs: 16 threads and the best count of this curve
         line = {
             "metric": f"Msamples/s (pixels x spp) on scene_random_spheres {W}x{H}",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -669,7 +818,19 @@ def main():
             "scan_valu": scan_valu, "ray_pool": ray_pool, "end_to_end": end_to_end, "depth16": depth16,
             "segments_per_sample": round(all_segments / (samples_per_step * args.steps), 4),
             "numerics": args.numerics, "numerics_legs": numerics_legs, "in_library_devices": in_lib,
+            "small_frames": small,
         }
+        # (the driver's record keeps the VALUES of `config` and `roofline`, of other objects only the key names: the rates a reader of
+        #  BENCH_rNN.json needs are repeated there)
+        if small and "error" not in small:
+            line["config"]["small_frames_Msamples_per_s"] = {k: {m: v[m]["Msamples_per_s"] for m in ("plain", "group_cull") if m in v}
+                                                             for k, v in small.items() if isinstance(v, dict) and "plain" in v}
+            line["config"]["small_frames_call_us_median"] = {k: v["plain"]["call_us_median"] for k, v in small.items() if isinstance(v, dict) and "plain" in v}
+        if accel:
+            line["roofline"]["accelerated_value"] = accel["value"]
+            line["roofline"]["accelerated_ms_per_step"] = accel["ms_per_step"]
+        if end_to_end:
+            line["roofline"]["value_end_to_end"] = end_to_end["value"]
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
         if cpu16:
@@ -693,7 +854,7 @@ def main():
         f64_4k["roofline"]["note_f64"] = ("pass 1 is the same binary32/f16 matrix-pipe filter in both precisions; FP64 arithmetic (two issue slots per "
                                           "instruction) only in pass 2 and shading, so the same issue bound applies")
         if not args.no_cpu_baseline:
-            legs4, _ = cpu_legs(w4, min(args.cpu_seconds, 8.0))
+            legs4, _ = cpu_legs(w4, min(args.cpu_seconds, 6.0), thread_counts=cpu_counts_short)
             f64_4k["cpu_baseline"] = max(legs4, key=lambda d: d["value"])
             f64_4k["gpu_over_cpu"] = round(f64_4k["value"] / f64_4k["cpu_baseline"]["value"], 1)
         w4.close()
@@ -713,7 +874,7 @@ def main():
         f64_pub["vs_published"] = {"published": PUBLISHED_MSAMPLES, "unit": "Msamples/s", "ratio": round(f64_pub["value"] / PUBLISHED_MSAMPLES, 1),
                                    "published_on": "Ryzen 3700 (8C/16T), julia -t 16, 1282.44 s -- DIFFERENT HARDWARE, context only (not `vs_baseline`)"}
         if not args.no_cpu_baseline:
-            legsp, _ = cpu_legs(wp, min(args.cpu_seconds, 8.0))
+            legsp, _ = cpu_legs(wp, min(args.cpu_seconds, 6.0), thread_counts=cpu_counts_short)
             f64_pub["cpu_baseline"] = max(legsp, key=lambda d: d["value"])
             f64_pub["gpu_over_cpu"] = round(f64_pub["value"] / f64_pub["cpu_baseline"]["value"], 1)
         wp.close()

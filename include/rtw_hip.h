@@ -24,9 +24,12 @@
 extern "C" {
 #endif
 
-#define RTW_ABI_VERSION 3   /* round 5: no field moved, but the DEFAULT image changed -- the deciding arithmetic of hit(::Sphere) is now the
-                               reference's own un-fused order (RTW_FLAG_NUMERICS_* below; version 2's image = RTW_FLAG_NUMERICS_CONTRACT) --
-                               and the measurement switches read from the environment are honoured only under RTW_ENABLE_TEST_AIDS=1 */
+#define RTW_ABI_VERSION 4   /* round 6: no field moved; two flags of version 3 are gone from the default library -- RTW_FLAG_NUMERICS_REFERENCE_FMA
+                               (64: a numerics mode no compiler was found to emit; the bit is now an unknown flag, -2) and RTW_FLAG_RAY_POOL (8:
+                               still defined, but the kernel is a `make POOL=1` build option; the default library answers -7) -- and the default
+                               chunk rule of rtw_params.n_chunks changed (below).  Version 3 (round 5): the DEFAULT image became the reference's
+                               own un-fused order of hit(::Sphere) (RTW_FLAG_NUMERICS_*; version 2's image = RTW_FLAG_NUMERICS_CONTRACT) and the
+                               measurement switches of the environment are honoured only under RTW_ENABLE_TEST_AIDS=1 */
 
 /* Material kinds: Lambertian / Metal / Dielectric (src/material.jl:3-5, 25-29, 37-39). */
 enum { RTW_LAMBERTIAN = 0, RTW_METAL = 1, RTW_DIELECTRIC = 2 };
@@ -95,14 +98,13 @@ typedef struct {
  * brighter by 0.003 in the mean (fewer tmin re-hits of the r = 1000 ground sphere); Float64 images agree to the last few ulps.
  *   default (neither bit)            `oc . r.dir` and `oc . oc` as StaticArrays' dot evaluates them -- (x1 y1 + x2 y2) + x3 y3, no FMA:
  *                                    a callee, which @fastmath does not rewrite --, c = oc.oc - r^2, disc = half_b^2 - c, one rounding each
- *   RTW_FLAG_NUMERICS_REFERENCE_FMA  the same with the last step contracted, disc = fma(half_b, half_b, -c): what an FMA target gives if
- *                                    the square carries LLVM's `contract` flag
- *   RTW_FLAG_NUMERICS_REFERENCE_FMA2 ... and c = fma(-r, r, oc.oc) as well: what LLVM emits for an FMA target when BOTH squares of lines 17-18 carry
+ *   RTW_FLAG_NUMERICS_REFERENCE_FMA2 the un-fused dots with BOTH squares contracted, disc = fma(half_b, half_b, -c) and c = fma(-r, r, oc.oc): what LLVM emits for an FMA target when BOTH squares of lines 17-18 carry
  *                                    fast-math flags (tools/llvm_fastmath_check/: with the flag-less llvm.powi of Julia's pow_fast neither site is fused)
  *   RTW_FLAG_NUMERICS_CONTRACT       ABI 2's arithmetic: half_b, r^2 - |oc|^2 and disc as three FMA chains
  * The bits exclude each other.  tools/julia_kat.jl + tools/check_julia_kat.py decide between them on a Julia box. */
 #define RTW_FLAG_NUMERICS_CONTRACT 32
-#define RTW_FLAG_NUMERICS_REFERENCE_FMA 64
+/* (64 was RTW_FLAG_NUMERICS_REFERENCE_FMA in ABI 3 -- only the last step contracted: removed in ABI 4, neither LLVM experiment of
+ *  tools/llvm_fastmath_check/ emits it; the bit is rejected as unknown) */
 #define RTW_FLAG_NUMERICS_REFERENCE_FMA2 128
 /* Measurement / test switches of the ENVIRONMENT (RTW_SCAN, RTW_POOL, RTW_JOB_PIXELS, RTW_ROWS_SHIFT, RTW_NO_HUGE,
  * RTW_DEBUG_REMOTE_SHARDS, RTW_DEBUG_NO_PEER, RTW_PHASE_PROFILE, RTW_DRAIN_PROFILE, RTW_DEBUG) are honoured only when the master switch
@@ -122,7 +124,8 @@ typedef struct {
     int32_t max_depth;    /* ray_color depth; reference default 16 (src/ray_color.jl:14)      */
     uint64_t seed;        /* render seed; the stream of (pixel, chunk) derives from it        */
     int32_t n_chunks;     /* sample chunks per pixel, each with its own RNG stream;
-                             0 = default rule min(spp, clamp(spp / 4, 16, 256)).  Part of the image definition
+                             0 = default rule min(spp, 256) (ABI <= 3: min(spp, clamp(spp / 4, 16, 256)): the default images of
+                             renders with 17 .. 1023 spp changed with ABI 4; 1000 spp: 250 chunks either way).  Part of the image definition
                              (the sample radiances themselves are added exactly, in any order). */
     int32_t shard_index;  /* this call renders the 8x8 pixel tiles t with                      */
     int32_t shard_count;  /*   t mod shard_count == shard_index; other pixels are written 0    */
@@ -207,7 +210,7 @@ int rtw_stats_devices(int32_t capacity, int32_t *count, int32_t *devices, double
  *       13 hit_world_mfma (pass 1 on the matrix pipe: the trace kernel's plain scan), scene staged in LDS;
  *          tmin of ray 0 serves the whole launch, tmax is +inf
  *       14 the same with block culling (RTW_FLAG_GROUP_CULL on the matrix pipe), cull layout staged in LDS
- *   bits 8-9 of `op`: the numerics mode of the ray-sphere test for ops 0, 8 - 11, 13, 14 (0 reference, 1 contract, 2 reference_fma, 3 reference_fma2)  */
+ *   bits 8-9 of `op`: the numerics mode of the ray-sphere test for ops 0, 8 - 11, 13, 14 (0 reference, 1 contract, 3 reference_fma2; 2 is rejected)  */
 int rtw_unit_f32(int op, int count, const void *in, void *out, const rtw_scene_f32 *scene,
                  const rtw_camera_f32 *cam);
 int rtw_unit_f64(int op, int count, const void *in, void *out, const rtw_scene_f64 *scene,

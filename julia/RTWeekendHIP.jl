@@ -47,7 +47,7 @@ end
 
 function __init__()
     v = ccall((:rtw_abi_version, LIB), Cint, ())
-    v == 3 || error("librtw_hip.so has ABI version $v; this shim binds version 3 (include/rtw_hip.h)")
+    v == 4 || error("librtw_hip.so has ABI version $v; this shim binds version 4 (include/rtw_hip.h)")
 end
 
 matkind(::Lambertian) = Int32(0)
@@ -71,16 +71,16 @@ Drop-in for `RayTracingWeekend.render` (src/render.jl:8-44) on MI355X.  Keyword 
 `devices=:all` uses every visible GPU, `devices=[0, 1, 2]` the listed ones (the 8x8 tiles are dealt
 round-robin to the devices inside the library; the image is identical for any device list).
 `numerics` selects the deciding arithmetic of `hit(::Sphere)` (src/hit.jl:16-18): `:reference` (default) = the reference's own order -- StaticArrays' un-fused
-`dot`, one rounding per written operation --, `:reference_fma` = the same with `disc = fma(half_b, half_b, -c)`, `:reference_fma2` = … and `c = fma(-r, r, oc⋅oc)`, `:contract` = three FMA chains
+`dot`, one rounding per written operation --, `:reference_fma2` = the same with both squares contracted, `disc = fma(half_b, half_b, -c)` and `c = fma(-r, r, oc⋅oc)`, `:contract` = three FMA chains
 (RTW_FLAG_NUMERICS_*; in Float32 the choice moves the image mean by 0.003 and the work by 4 %: `tools/julia_kat.jl` tells which one this Julia build emits).
 `group_cull=true` selects the opt-in culling scan (RTW_FLAG_GROUP_CULL), `scan_valu=true` the all-VALU form of either
-scan (RTW_FLAG_SCAN_VALU, for A/B measurements), `ray_pool=true` the ray-pool kernel (RTW_FLAG_RAY_POOL): same image bit for bit in every mode.
+scan (RTW_FLAG_SCAN_VALU, for A/B measurements): same image bit for bit in every mode; `ray_pool=true` (RTW_FLAG_RAY_POOL) needs a `make POOL=1` build of the library.
 `rccl_reduce=true` (with `devices`): the shards are put together by one ncclReduce inside the library (RTW_FLAG_RCCL_REDUCE) instead of peer copies.
 """
 function render(scene::HittableList, cam::Camera{T}, image_width=400, n_samples=1;
                 depth=16, seed=1, n_chunks=0, device=-1, devices=nothing, numerics=:reference, group_cull=false, scan_valu=false, ray_pool=false, rccl_reduce=false) where T <: Union{Float32,Float64}
-    numerics in (:reference, :contract, :reference_fma, :reference_fma2) || throw(ArgumentError("numerics must be :reference, :contract, :reference_fma or :reference_fma2"))
-    nflags = numerics === :contract ? 32 : numerics === :reference_fma ? 64 : numerics === :reference_fma2 ? 128 : 0         # RTW_FLAG_NUMERICS_CONTRACT / _REFERENCE_FMA / _REFERENCE_FMA2
+    numerics in (:reference, :contract, :reference_fma2) || throw(ArgumentError("numerics must be :reference, :contract or :reference_fma2"))
+    nflags = numerics === :contract ? 32 : numerics === :reference_fma2 ? 128 : 0         # RTW_FLAG_NUMERICS_CONTRACT / _REFERENCE_FMA2
     image_height = image_width ÷ (16//9)                       # src/render.jl:11-12
     n = length(scene)
     cx = Vector{T}(undef, n); cy = similar(cx); cz = similar(cx); r = similar(cx)

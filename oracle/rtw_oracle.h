@@ -32,8 +32,9 @@
  *   - NUMERICS MODES (rtwo_params.numerics; rtwo_set_numerics for the unit-level exports): the other evaluations an
  *     LLVM build of that function could produce, kept selectable so that one Julia run decides (tools/julia_kat.jl):
  *        RTW_NUMERICS_CONTRACT        rounds 1-4: half_b, r^2 - |oc|^2 and disc as three FMA chains
- *        RTW_NUMERICS_REFERENCE_FMA   un-fused dots, disc = fma(half_b, half_b, -c)
- *        RTW_NUMERICS_REFERENCE_FMA2  ... and c = fma(-r, r, oc.oc) too          (oracle only)
+ *        RTW_NUMERICS_REFERENCE_FMA   un-fused dots, disc = fma(half_b, half_b, -c)   (oracle only since round 6: a mode of the library until ABI 3;
+ *                                     kept here so that tools/check_julia_kat.py can still name it if a Julia build turns out to emit it)
+ *        RTW_NUMERICS_REFERENCE_FMA2  ... and c = fma(-r, r, oc.oc) too
  *     In Float32 the choice is NOT noise: the contract form traces 4 % fewer segments per sample on
  *     scene_random_spheres and shifts the image mean by +0.003 (fewer tmin re-hits of the r = 1000 ground sphere).
  *   - Float32 mode is the reference's *mixed* precision: geometry, RNG floats and

@@ -133,7 +133,7 @@ def _p(a):
 
 def default_n_chunks(spp):
     """the device's default rule (include/rtw_hip.h rtw_params.n_chunks)"""
-    return min(int(spp), max(16, min(256, int(spp) // 4)))
+    return min(int(spp), 256)
 
 
 def make_scene(flat, T):

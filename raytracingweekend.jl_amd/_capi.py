@@ -124,20 +124,19 @@ FLAG_SCAN_VALU = 4       # include/rtw_hip.h RTW_FLAG_SCAN_VALU
 FLAG_RAY_POOL = 8        # include/rtw_hip.h RTW_FLAG_RAY_POOL
 FLAG_RCCL_REDUCE = 16    # include/rtw_hip.h RTW_FLAG_RCCL_REDUCE
 FLAG_NUMERICS_CONTRACT = 32        # include/rtw_hip.h RTW_FLAG_NUMERICS_CONTRACT
-FLAG_NUMERICS_REFERENCE_FMA = 64   # include/rtw_hip.h RTW_FLAG_NUMERICS_REFERENCE_FMA
 FLAG_NUMERICS_REFERENCE_FMA2 = 128  # include/rtw_hip.h RTW_FLAG_NUMERICS_REFERENCE_FMA2
 GATHER_PEER, GATHER_HOST_STAGED, GATHER_RCCL, GATHER_SAME_DEVICE = 1, 2, 4, 8    # rtw_stats_t.gather_path bits
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # The deciding arithmetic of the ray-sphere test (src/hit.jl:16-18; include/rtw_hip.h RTW_FLAG_NUMERICS_*).
 # name -> (rtw_params.flags bits, the mode code in bits 8-9 of a unit op)
-NUMERICS = {"reference": (0, 0), "contract": (FLAG_NUMERICS_CONTRACT, 1), "reference_fma": (FLAG_NUMERICS_REFERENCE_FMA, 2),
-            "reference_fma2": (FLAG_NUMERICS_REFERENCE_FMA2, 3)}
+NUMERICS = {"reference": (0, 0), "contract": (FLAG_NUMERICS_CONTRACT, 1), "reference_fma2": (FLAG_NUMERICS_REFERENCE_FMA2, 3)}
 _default_numerics = "reference"
 
 
 def set_default_numerics(name):
-    """The mode ``render`` / ``DeviceRenderer`` / ``make_params`` use when none is named.  Returns the previous default."""
+    """TEST HELPER (tests/conftest.py runs every parity module once per mode with it) -- process-wide, not for product code: name the mode
+    per call instead.  The mode ``render`` / ``DeviceRenderer`` / ``make_params`` use when none is named.  Returns the previous default."""
     global _default_numerics
     if name not in NUMERICS:
         raise ValueError(f"numerics must be one of {sorted(NUMERICS)}")
@@ -163,13 +162,17 @@ def numerics_unit_bits(numerics=None):
 
 def make_params(width, height, spp, max_depth=16, seed=1, n_chunks=0, shard_index=0, shard_count=1,
                 device=-1, gamma=1, flags=0, devices=None, job_pixels=0, numerics=None):
-    """``numerics``: "reference" (default) / "contract" / "reference_fma" / "reference_fma2", or None = the module default
-    (``set_default_numerics``); ignored when ``flags`` already names a mode.
+    """``numerics``: "reference" (default) / "contract" / "reference_fma2", or None = the module default
+    (``set_default_numerics``).  ``flags`` may name the mode instead (a NUMERICS bit); naming a DIFFERENT mode both ways is a ValueError
+    (the mode changes the image: it is never overridden silently).
     ``devices``: None / int ordinal -> one device; "all" -> every visible device (n_devices = -1);
     a sequence of ordinals -> that device list (host-buffer entry points only)."""
     flags = int(flags)
-    if not flags & (FLAG_NUMERICS_CONTRACT | FLAG_NUMERICS_REFERENCE_FMA | FLAG_NUMERICS_REFERENCE_FMA2):
+    named = flags & (FLAG_NUMERICS_CONTRACT | FLAG_NUMERICS_REFERENCE_FMA2)
+    if not named:
         flags |= numerics_flags(numerics)
+    elif numerics is not None and numerics_flags(numerics) != named:
+        raise ValueError(f"numerics={numerics!r} conflicts with the NUMERICS bit already in flags (0x{named:x})")
     P = Params(int(width), int(height), int(spp), int(max_depth), int(seed), int(n_chunks),
                int(shard_index), int(shard_count), int(device), int(gamma), flags, 0, int(job_pixels), None)
     if devices is None:

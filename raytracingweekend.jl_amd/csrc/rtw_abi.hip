@@ -58,7 +58,7 @@ int acquire_rec(DeviceCtx *ctx, RenderRec **out) {
     for (auto &r : ctx->recs) {
         if (r->owned) continue;
         if (r->used && !r->done) {
-            if (hipEventQuery(r->ev1) != hipSuccess) { (void)hipGetLastError(); continue; }   // still in flight
+            if (hipEventQuery(r->ev2) != hipSuccess) { (void)hipGetLastError(); continue; }   // still in flight
             r->done = true;
         }
         r->owned = true;
@@ -68,8 +68,11 @@ int acquire_rec(DeviceCtx *ctx, RenderRec **out) {
     std::unique_ptr<RenderRec> r(new RenderRec());
     r->device = ctx->device;
     HIP_TRY(hipMalloc(&r->ctr, sizeof(rtw::DevCounters)));
+    HIP_TRY(hipHostMalloc((void **)&r->h_ctr, sizeof(rtw::DevCounters), hipHostMallocDefault));
+    HIP_TRY(hipMemset(r->ctr, 0, sizeof(rtw::DevCounters)));           // (a render clears the head only, unless it profiles the drain)
     HIP_TRY(hipEventCreate(&r->ev0));
     HIP_TRY(hipEventCreate(&r->ev1));
+    HIP_TRY(hipEventCreateWithFlags(&r->ev2, hipEventDisableTiming));
     r->owned = true;
     *out = r.get();
     ctx->recs.push_back(std::move(r));
@@ -117,12 +120,15 @@ int validate_params(const rtw_params *p, int *n_chunks, int *chunk_spp) {
     if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(-2, "bad shard %d of %d", p->shard_index, p->shard_count);
     if (p->n_chunks < 0) return fail(-2, "n_chunks must be >= 0");
-    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_RAY_POOL | RTW_FLAG_RCCL_REDUCE | RTW_FLAG_NUMERICS_CONTRACT | RTW_FLAG_NUMERICS_REFERENCE_FMA | RTW_FLAG_NUMERICS_REFERENCE_FMA2)) return fail(-2, "unknown flags 0x%x", p->flags);
-    { const int nm = p->flags & (RTW_FLAG_NUMERICS_CONTRACT | RTW_FLAG_NUMERICS_REFERENCE_FMA | RTW_FLAG_NUMERICS_REFERENCE_FMA2);
+    if (p->flags & ~(RTW_FLAG_GROUP_CULL | RTW_FLAG_COMPACT_TILES | RTW_FLAG_SCAN_VALU | RTW_FLAG_RAY_POOL | RTW_FLAG_RCCL_REDUCE | RTW_FLAG_NUMERICS_CONTRACT | RTW_FLAG_NUMERICS_REFERENCE_FMA2)) return fail(-2, "unknown flags 0x%x", p->flags);
+    { const int nm = p->flags & (RTW_FLAG_NUMERICS_CONTRACT | RTW_FLAG_NUMERICS_REFERENCE_FMA2);
       if (nm & (nm - 1)) return fail(-2, "the RTW_FLAG_NUMERICS_* bits exclude each other (flags 0x%x)", p->flags); }
-    // default rule: about 4 samples per chunk, between 16 and 256 chunks (never more than spp):
-    // enough items for load balance, few enough stream set-ups (1 sample per chunk costs 7 % at Float64)
-    int nch = p->n_chunks > 0 ? p->n_chunks : std::min(p->spp, std::max(16, std::min(256, p->spp / 4)));
+    // default rule (ABI 4): one sample per chunk up to 256 chunks -- min(spp, 256).  The finer the items, the shorter the tail of a frame
+    // and the less a job slot waits for a straggler; a chunk's stream set-up is made by the whole wave for a batch at a time.  Measured
+    // (round 6, new scheduler; 4-sample chunks -> 1-sample chunks): 1080p x 64 spp 28.6 -> 24.9 ms, 1080p x 200 spp 76.0 -> 74.6 ms,
+    // 320 x 180 x 64 spp 1.26 -> 0.84 ms, Float64 1080p x 200 spp 56.8 -> 57.0 ms.  1000 spp: 250 chunks of 4 under both rules.
+    // (ABI <= 3: min(spp, clamp(spp / 4, 16, 256)).)
+    int nch = p->n_chunks > 0 ? p->n_chunks : std::min(p->spp, 256);
     if (nch > p->spp) nch = p->spp;
     int cs = (p->spp + nch - 1) / nch;
     *chunk_spp = cs;
@@ -234,19 +240,23 @@ int rtw_unit_f64(int op, int count, const void *in, void *out, const rtw_scene_f
 
 int rtw_shutdown(void) {
     DeviceGuard guard;
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_generation.fetch_add(1);                 // every thread's "last render" is now stale (rtw_stats reports -6)
-    for (auto &c : g_ctx) {
-        HIP_IGNORE(hipSetDevice(c->device));
-        std::lock_guard<std::mutex> lk2(c->mu);
-        // Records that some thread still references (`owned`: a host render in flight on another thread, or a thread's last render)
-        // are NOT destroyed here: that thread holds a CtxPtr, the DeviceCtx -- and with it these records -- lives until it lets go.
-        c->recs.erase(std::remove_if(c->recs.begin(), c->recs.end(), [](const std::unique_ptr<RenderRec> &r) { return !r->owned; }), c->recs.end());
-        // (host contexts in use by a render in flight on another thread stay alive with their DeviceCtx in the same way)
-        c->host.erase(std::remove_if(c->host.begin(), c->host.end(), [](const std::unique_ptr<HostCtx> &h) { return !h->busy; }), c->host.end());
+    {
+        // g_mu is held for the context table only: a render that owns an RCCL communicator set takes g_mu (get_ctx) while it holds the
+        // set, so waiting for that set below with g_mu held would be a lock-order inversion (render: set -> g_mu; shutdown: g_mu -> set)
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_generation.fetch_add(1);                 // every thread's "last render" is now stale (rtw_stats reports -6)
+        for (auto &c : g_ctx) {
+            HIP_IGNORE(hipSetDevice(c->device));
+            std::lock_guard<std::mutex> lk2(c->mu);
+            // Records that some thread still references (`owned`: a host render in flight on another thread, or a thread's last render)
+            // are NOT destroyed here: that thread holds a CtxPtr, the DeviceCtx -- and with it these records -- lives until it lets go.
+            c->recs.erase(std::remove_if(c->recs.begin(), c->recs.end(), [](const std::unique_ptr<RenderRec> &r) { return !r->owned; }), c->recs.end());
+            // (host contexts in use by a render in flight on another thread stay alive with their DeviceCtx in the same way)
+            c->host.erase(std::remove_if(c->host.begin(), c->host.end(), [](const std::unique_ptr<HostCtx> &h) { return !h->busy; }), c->host.end());
+        }
+        g_ctx.clear();
     }
-    g_ctx.clear();
-    rccl_shutdown();           // (waits for a render that is using a communicator set)
+    rccl_shutdown();           // (waits for a render that is using a communicator set; g_mu is NOT held here)
     return 0;
 }
 

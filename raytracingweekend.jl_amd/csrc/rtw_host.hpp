@@ -99,13 +99,17 @@ struct DeviceGuard {
 struct RenderRec {
     int device = -1;
     rtw::DevCounters *ctr = nullptr;     // device memory
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    rtw::DevCounters *h_ctr = nullptr;   // pinned host copy: filled by an asynchronous D2H behind the kernel on the render's stream (no blocking copy per render)
+    size_t ctr_bytes = 0;                // how much of it that copy brought over (the head; everything with the drain profile)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;      // around the kernel; behind the copy of the counters
     bool used = false;                   // ev1 has been recorded at least once
     bool done = true;                    // the kernel recorded by ev1 is known to have finished (no hipEventQuery needed)
     bool owned = false;                  // referenced by some thread's "last render"
     int n_spheres = 0, n_chunks = 0, grid = 0, block = 256;
     ~RenderRec() {
         if (ctr) HIP_IGNORE(hipFree(ctr));
+        if (h_ctr) HIP_IGNORE(hipHostFree(h_ctr));
+        if (ev2) HIP_IGNORE(hipEventDestroy(ev2));
         if (ev0) HIP_IGNORE(hipEventDestroy(ev0));
         if (ev1) HIP_IGNORE(hipEventDestroy(ev1));
     }
@@ -133,6 +137,7 @@ struct DeviceCtx {
     int device = -1;
     int num_cus = 0;
     size_t lds_per_cu = 0;                         // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor (160 KB on MI355X)
+    std::vector<std::pair<std::pair<const void *, size_t>, int>> occupancy;   // (kernel, dynamic LDS) -> workgroups per CU (asked of the runtime once; guarded by mu)
     std::mutex mu;
     std::vector<std::unique_ptr<RenderRec>> recs;
     std::vector<std::unique_ptr<HostCtx>> host;    // at most RTW_HOST_CTX_POOL cached entries

@@ -29,7 +29,8 @@ namespace rtw {
 #define RTW_REF_BITS 9       // item reference = slot (5 bits) << 4 | pixel (4 bits)
 #define RTW_REF_MASK 511u
 #define RTW_SLOT_FREE 0xffffffffu
-#define RTW_SLOT_OPENING 0xfffffffeu
+#define RTW_SLOT_OPENING 0xfffffffeu       // (the ray-pool kernel's marker)
+#define RTW_SLOT_OPENING_BIT 0x80000000u   // lane loop: ready_seq = this bit + the job's sequence number while its opener claims the job
 #define RTW_JOB_EOF 0xffffffffu
 
 struct KParams {
@@ -53,13 +54,14 @@ struct KParams {
     unsigned div_bpj_m, div_bpj_s, div_tiles_m, div_tiles_s;
     int gamma;
     int out_layout;        // 0: Matrix{RGB{T}} column-major full frame; 1: compact, tile-major, this shard only
+    int drain_profile;     // RTW_DRAIN_PROFILE (test aid): the workgroups report their waves' end clocks (DevCounters::t_first ...)
 };
 
 struct DevCounters {
     unsigned next_job[8];          // one job queue per XCD (claim_job)
     unsigned long long segments;
     unsigned long long samples;
-    unsigned long long phase[8];   // RTW_PHASE_PROFILE=1 only: wave-cycles per phase (s_memtime)
+    unsigned long long phase[16];  // RTW_PHASE_PROFILE=1 only: wave-cycles per phase (s_memtime) [0..5], event counters [6..15]
     unsigned long long t_first, t_last, t_end_sum, n_waves;   // wall clock (100 MHz) of the first wave start, the last wave
                                                               // end and the sum of all wave ends: the end-of-queue drain
     unsigned end_hist[4096];                                  // waves by end time since t_first, 0.25 ms bins (RTW_DRAIN_PROFILE)
@@ -80,11 +82,12 @@ struct JobSlot {
     __device__ __forceinline__ const unsigned long long *acc(unsigned px) const { return reinterpret_cast<const unsigned long long *>(this + 1) + 8u * px; }
 };
 static_assert(sizeof(JobSlot) == 128, "JobSlot header is 128 bytes (16-byte aligned accumulators follow)");
-struct JobCache { unsigned long long jc; unsigned jc_lock; unsigned queue_off; unsigned last_g; unsigned pad; };       // see claim_job
+struct JobCache { unsigned long long jc; unsigned jc_lock; unsigned queue_off; unsigned last_g; unsigned static_used; };       // see claim_job
 template <typename T> struct WgShared {
     unsigned char slots[RTW_SLOT_BYTES];      // n_slots x (128-byte JobSlot + 64 bytes per job pixel)
     __device__ __forceinline__ JobSlot *slot(unsigned i, unsigned stride) { return reinterpret_cast<JobSlot *>(slots + i * stride); }
     unsigned ticket;                         // next batch of this workgroup
+    unsigned eof;                            // an opener found every job queue exhausted (lane loop; see the slot protocol there)
     unsigned fin_waves;                      // waves of this workgroup that have finished, and what they counted: the last one adds
     unsigned long long fin_segments, fin_samples;   // it to DevCounters (one pair of global atomics per workgroup, not per wave)
     unsigned long long t_wave[8];            // wall clock at the start [0..3] and the end [4..7] of each wave (RTW_DRAIN_PROFILE)
@@ -96,12 +99,12 @@ template <typename T> struct WgShared {
 // Phase profiler (opt-in instantiation, never used for timed runs): s_memtime stamps around
 // the phases of the lane loop, summed per wave.
 template <bool ON> struct PhaseClock {
-    unsigned long long t0 = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t0 = 0, acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     __device__ __forceinline__ void start() { if (ON) t0 = __builtin_readcyclecounter(); }
     __device__ __forceinline__ void lap(int k) {
         if (ON) { unsigned long long t = __builtin_readcyclecounter(); acc[k] += t - t0; t0 = t; }
     }
-    __device__ __forceinline__ void count(int k, unsigned n) { if (ON) acc[k] += n; }      // event counters in the spare cells 6, 7
+    __device__ __forceinline__ void count(int k, unsigned n) { if (ON) acc[k] += n; }      // event counters in the cells 6 .. 15
 };
 
 __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned s) {
@@ -239,8 +242,30 @@ __device__ __forceinline__ unsigned queue_positions(const KParams &P, unsigned x
 #ifndef RTW_CLAIM_TAIL
 #define RTW_CLAIM_TAIL 16u
 #endif
+// Static first claims.  The first RTW_STATIC_CLAIMS claims of a workgroup take no atomic at all: workgroup b owns positions
+// (b >> 3) K .. (b >> 3) K + K - 1 of queue b & 7 (its own die's, with the hardware's round-robin placement), and what the atomic counters
+// hand out starts behind the static part of each queue (static_base).  At the start of a render every wave of the chip wants a job at
+// once: 5 120 returning atomics on 8 addresses are executed one after the other by the memory side -- measured on a 96 x 54 frame:
+// 166 us of kernel time with them, 64 us with jobs so large that a quarter as many were claimed; on 320 x 180 x 64 spp the start-up is
+// 10 % of the frame.  (Which workgroup renders which job does not matter to the image.)
+#ifndef RTW_STATIC_CLAIMS
+#define RTW_STATIC_CLAIMS 4u
+#endif
+// (a queue shorter than RTW_STATIC_CLAIMS x its workgroups deals fewer -- possibly no -- static positions per workgroup: every workgroup
+//  of the queue gets the same number, the rest goes through the counter)
+__device__ __forceinline__ unsigned static_claims(unsigned xq, unsigned q_pos) {
+    const unsigned wgs = (gridDim.x + 7u - xq) >> 3;                  // workgroups b with b & 7 == xq
+    const unsigned k = wgs ? q_pos / wgs : 0u;
+    return k < RTW_STATIC_CLAIMS ? k : RTW_STATIC_CLAIMS;
+}
+__device__ __forceinline__ unsigned static_base(unsigned xq, unsigned q_pos) { return static_claims(xq, q_pos) * ((gridDim.x + 7u - xq) >> 3); }
 __device__ __forceinline__ bool claim_job(const KParams &P, DevCounters *ctr, JobCache *C, unsigned xcd, unsigned sub_shift, unsigned &xq_out, unsigned &gq_out) {
     constexpr unsigned long long M28 = (1ull << 28) - 1ull;
+    if (__hip_atomic_load(&C->static_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < RTW_STATIC_CLAIMS) {
+        const unsigned k = __hip_atomic_fetch_add(&C->static_used, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned xq = blockIdx.x & 7u, ks = static_claims(xq, queue_positions(P, xq, sub_shift));
+        if (k < ks) { xq_out = xq; gq_out = (blockIdx.x >> 3) * ks + k; return true; }
+    }
     for (;;) {
         unsigned long long w = __hip_atomic_load(&C->jc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         while ((w & M28) < ((w >> 28) & M28)) {                    // cached positions: take one
@@ -267,7 +292,7 @@ __device__ __forceinline__ bool claim_job(const KParams &P, DevCounters *ctr, Jo
             const unsigned seen = __hip_atomic_load(&C->last_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), left = q_pos > seen ? q_pos - seen : 0u;
             unsigned n = 1u;
             if (locked && off == 0u) { n = left / (RTW_CLAIM_TAIL * (gridDim.x / 8u + 1u)); n = n > RTW_JOB_CLAIM ? RTW_JOB_CLAIM : n < 1u ? 1u : n; }
-            const unsigned g0 = atomicAdd(&ctr->next_job[xq], n);
+            const unsigned g0 = atomicAdd(&ctr->next_job[xq], n) + static_base(xq, q_pos);         // (behind the queue's static part)
             if (off == 0u) __hip_atomic_store(&C->last_g, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (any wave's: a recent position)
             if (g0 >= q_pos) { off += 1u; continue; }            // this queue is exhausted (for good): the next die's
             xq_out = xq; gq_out = g0; got = true;
@@ -359,7 +384,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
     // (CULL on the matrix pipe: the tables of the block vote behind the index list)
     [[maybe_unused]] unsigned *lds_tab = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(lds_orig) + (CULL ? ((size_t)cull_exact_count(cull) * sizeof(unsigned short) + 15) / 16 * 16 : 0));
     if (threadIdx.x < P_arg.n_slots) { JobSlot *S0 = sh->slot(threadIdx.x, P_arg.slot_stride); S0->ready_seq = RTW_SLOT_FREE; S0->job = 0u; }
-    if (threadIdx.x == 0) { sh->ticket = 0u; sh->fin_waves = 0u; sh->fin_segments = 0ull; sh->fin_samples = 0ull; sh->jobs.jc = 0ull; sh->jobs.jc_lock = 0u; sh->jobs.queue_off = 0u; sh->jobs.last_g = 0u; sh->cam = cam_arg; sh->P = P_arg; }
+    if (threadIdx.x == 0) { sh->ticket = 0u; sh->eof = 0u; sh->fin_waves = 0u; sh->fin_segments = 0ull; sh->fin_samples = 0ull; sh->jobs.jc = 0ull; sh->jobs.jc_lock = 0u; sh->jobs.queue_off = 0u; sh->jobs.last_g = 0u; sh->jobs.static_used = 0u; sh->cam = cam_arg; sh->P = P_arg; }
     const KParams &P = sh->P;
     if (LDS_SCENE) {
         if (CULL) stage_cull_scene<T>(cull, lds_geom, lds_orig);
@@ -424,6 +449,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         }
         n_segments += (unsigned long long)__popcll(__ballot(has_ray));
         clk.lap(2);
+        if (PROFILE) { clk.count(8, 1u); clk.count(9, (unsigned)__popcll(__ballot(has_ray))); if (!__any(has_ray)) clk.count(10, 1u); }      // lane loop iterations, lanes with a ray, iterations without any
 
         // ---- (H1) a miss ends the sample: its radiance thr * sky (src/ray_color.jl:36) is added EXACTLY
         //      to the pixel's accumulators in LDS (a path that runs out of depth adds 0: nothing to do) ----
@@ -432,11 +458,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             // About a quarter of the lanes end a path per iteration, and each has three channels to convert and add: instead
             // of three rounds at ~25 % lane utilisation the (lane, channel) tasks are dealt to ALL lanes through the wave's
             // candidate list area in LDS (free between two scans): one round for up to 21 paths.
-#ifdef RTW_PROBE_NO_ACCUM   // time probe (WRONG image: black): nothing is added to the pixels -- what the miss path (sky, fixed-point conversion, LDS atomics) costs
-            const bool miss = false;
-#else
-            const bool miss = has_ray && idx < 0;
-#endif
+            const bool miss = RTW_PROBE_MISS(has_ray && idx < 0);
             const unsigned long long miss_mask = __ballot(miss);
             if (miss_mask) {
                 unsigned char *scr = reinterpret_cast<unsigned char *>(ws.pairs);
@@ -486,63 +508,89 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                 store_job<T>(P, S, lane, out);
                 __hip_atomic_store(&S->ready_seq, RTW_SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            // a wave without unassigned items draws a batch ticket and tries to make it usable
-            if (pool_next >= pool_end) {
-                if (!have_ticket) {
-                    unsigned t = 0;
-                    if (lane == 0) t = __hip_atomic_fetch_add(&sh->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    t = uniform(t);
-                    tk_seq = udiv_magic(t, P.div_bpj_m, P.div_bpj_s);
-                    tk_b = t - tk_seq * P.bpj;
-                    have_ticket = true;
-                }
-                const unsigned sl = tk_seq - udiv_magic(tk_seq, P.div_slots_m, P.div_slots_s) * P.n_slots;   // tk_seq mod n_slots
-                JobSlot *S = sh->slot(sl, P.slot_stride);
-                unsigned rs = uniform(__hip_atomic_load(&S->ready_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (rs == RTW_SLOT_FREE && tk_b == 0u) {
-                    // this wave opens the job: claim the slot, take a job from the global queue, zero the accumulators
-                    unsigned won = 0;
-                    if (lane == 0) {
-                        unsigned expect = RTW_SLOT_FREE;
-                        won = __hip_atomic_compare_exchange_strong(&S->ready_seq, &expect, RTW_SLOT_OPENING, __ATOMIC_ACQUIRE,
-                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+            // Items for the lanes that need one: from the wave's current batch; when that runs out (or there is none) the wave draws a
+            // batch ticket, makes it usable (finds or opens the job's slot) and serves the remaining takers in the same iteration -- a
+            // lane that finds the pool short would otherwise sit out a whole scan (measured: 1 - 9 % of all lane-iterations).
+            // Job slots are allocated OUT OF ORDER: job `seq` lives in whichever slot its opener found free, and every ticket of the
+            // job finds it by its sequence number (lane l looks at slot l).  A slot is held until the job's last item is done -- a
+            // straggler (a 50-bounce path inside the glass sphere) holds ITS slot only; with the slots used as a ring it blocked every
+            // later job of the workgroup (measured at 1080p: 11 % of the lane-iterations lost at 200 spp, 69 % at 64 spp).
+            //   ready_seq:  RTW_SLOT_FREE | RTW_SLOT_OPENING_BIT + seq (its opener is claiming a job) | seq (open)
+            //   sh->eof:    set, before the slot is given back, by an opener whose claim found every queue exhausted.  Claims fail
+            //               for good once one has failed, and an opener advertises its slot BEFORE it claims: a wave that reads eof
+            //               first and then finds its job neither open nor opening knows that the job does not exist.
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round) {
+                const bool taker = need && alive && !have_item;
+                const unsigned long long take_mask = __ballot(taker);
+                if (!take_mask) break;
+                if (pool_next >= pool_end) {
+                    if (!have_ticket) {
+                        unsigned t = 0;
+                        if (lane == 0) t = __hip_atomic_fetch_add(&sh->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        t = uniform(t);
+                        tk_seq = udiv_magic(t, P.div_bpj_m, P.div_bpj_s);
+                        tk_b = t - tk_seq * P.bpj;
+                        have_ticket = true;
                     }
-                    if (uniform(won)) {
-                        open_job(P, S, lane, ctr, &sh->jobs);
-                        __hip_atomic_store(&S->ready_seq, tk_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        rs = tk_seq;
-                    }
-                }
-                if (rs < RTW_SLOT_OPENING) {
-                    if (uniform(S->job) == RTW_JOB_EOF) {
-                        // the global queue is exhausted (this slot stays marked for good): these lanes are done
-                        if (need) alive = false;
-                        have_ticket = false;
-                    } else if (rs == tk_seq) {
-                        pool_slot = sl; pool_b = tk_b;
-                        pool_next = 0; pool_end = 64;
-                        have_ticket = false;
-                        if constexpr (MFMA) {
-                            // Lane l prepares item l of the batch: setting up a stream is 2 splitmix64 + 1 step (~60 VALU), and a
-                            // wave takes items a few lanes at a time -- almost every iteration for ~6 % of its lanes.
-                            const unsigned px = lane & ((1u << P.job_shift) - 1u), chunk = tk_b * (64u >> P.job_shift) + (lane >> P.job_shift);
-                            const unsigned rs = P.rows_shift;
-                            const int i0 = S->i_base + (int)(px & ((1u << rs) - 1u)), j0 = S->j_base + (int)(px >> rs);
-                            Rng r0;
-                            rng_stream(P.seed, (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0, chunk, r0);
-                            pool_rng[lane] = ulonglong2{r0.x, r0.y};
-                            pool_valid = __ballot((int)chunk < P.n_chunks && ((S->valid >> px) & 1u));
-                            __builtin_amdgcn_wave_barrier();
+                    const unsigned eof = uniform(__hip_atomic_load(&sh->eof, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));     // (read BEFORE the slots)
+                    unsigned rs = RTW_SLOT_OPENING;                            // (0xfffffffe: matches neither a sequence number < 2^31 nor one with the opening bit)
+                    if (lane < P.n_slots) rs = __hip_atomic_load(&sh->slot(lane, P.slot_stride)->ready_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    unsigned long long m_mine = __ballot(rs == tk_seq);
+                    const unsigned long long m_opening = __ballot(rs == (tk_seq | RTW_SLOT_OPENING_BIT)), m_free = __ballot(rs == RTW_SLOT_FREE);
+                    unsigned sl = 0;
+                    if (!m_mine && !m_opening && !eof && tk_b == 0u && m_free) {
+                        // this wave opens the job: take a free slot, claim a job from the global queues, zero the accumulators
+                        sl = (unsigned)__builtin_ctzll(m_free);
+                        JobSlot *S = sh->slot(sl, P.slot_stride);
+                        unsigned won = 0;
+                        if (lane == 0) {
+                            unsigned expect = RTW_SLOT_FREE;
+                            won = __hip_atomic_compare_exchange_strong(&S->ready_seq, &expect, tk_seq | RTW_SLOT_OPENING_BIT, __ATOMIC_ACQ_REL,
+                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
                         }
+                        if (uniform(won)) {
+                            open_job(P, S, lane, ctr, &sh->jobs);
+                            if (uniform(S->job) == RTW_JOB_EOF) {
+                                if (lane == 0) __hip_atomic_store(&sh->eof, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(&S->ready_seq, RTW_SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (taker) alive = false;                     // the global queues are exhausted: these lanes are done
+                                have_ticket = false;
+                                break;
+                            }
+                            __hip_atomic_store(&S->ready_seq, tk_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            m_mine = 1ull << sl;
+                        }
+                        // (lost the slot to another opener: look again in the next iteration)
+                    } else if (!m_mine && !m_opening && eof) {
+                        if (taker) alive = false;                             // the job of this ticket does not exist: the queues are exhausted
+                        have_ticket = false;
+                        break;
+                    }
+                    if (!m_mine) break;                                       // the job is not open yet / no slot is free: try again in the next iteration
+                    sl = (unsigned)__builtin_ctzll(m_mine);
+                    const JobSlot *S = sh->slot(sl, P.slot_stride);
+                    pool_slot = sl; pool_b = tk_b;
+                    pool_next = 0; pool_end = 64;
+                    have_ticket = false;
+                    if constexpr (MFMA) {
+                        // Lane l prepares item l of the batch: setting up a stream is 2 splitmix64 + 1 step (~60 VALU), and a
+                        // wave takes items a few lanes at a time -- almost every iteration for ~6 % of its lanes.
+                        const unsigned px = lane & ((1u << P.job_shift) - 1u), chunk = tk_b * (64u >> P.job_shift) + (lane >> P.job_shift);
+                        const unsigned rsh = P.rows_shift;
+                        const int i0 = S->i_base + (int)(px & ((1u << rsh) - 1u)), j0 = S->j_base + (int)(px >> rsh);
+                        Rng r0;
+                        rng_stream(P.seed, (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0, chunk, r0);
+                        __builtin_amdgcn_wave_barrier();                      // (the previous batch's states have all been read)
+                        pool_rng[lane] = ulonglong2{r0.x, r0.y};
+                        pool_valid = __ballot((int)chunk < P.n_chunks && ((S->valid >> px) & 1u));
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
-            }
-            // hand out items of the wave's batch: item p = (pixel p mod job_px, chunk (64 / job_px) b + p / job_px)
-            const unsigned long long take_mask = __ballot(need && alive);
-            if (take_mask && pool_next < pool_end) {
+                // hand out items of the wave's batch: item p = (pixel p mod job_px, chunk (64 / job_px) b + p / job_px)
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(take_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)take_mask, 0u));   // takers below this lane
                 const unsigned p = pool_next + rank;
-                if (need && alive && p < pool_end) {
+                if (taker && p < pool_end) {
                     const JobSlot *S = sh->slot(pool_slot, P.slot_stride);
                     const unsigned px = p & ((1u << P.job_shift) - 1u), chunk = pool_b * (64u >> P.job_shift) + (p >> P.job_shift);
                     bool real;
@@ -553,8 +601,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                             const ulonglong2 st = pool_rng[p];
                             rng.x = st.x; rng.y = st.y;
                         } else {
-                            const unsigned rs = P.rows_shift;
-                            const int i0 = S->i_base + (int)(px & ((1u << rs) - 1u)), j0 = S->j_base + (int)(px >> rs);
+                            const unsigned rsh = P.rows_shift;
+                            const int i0 = S->i_base + (int)(px & ((1u << rsh) - 1u)), j0 = S->j_base + (int)(px >> rsh);
                             const unsigned long long pix = (unsigned long long)j0 * (unsigned)P.height + (unsigned)i0;
                             rng_stream(P.seed, pix, chunk, rng);
                         }
@@ -566,8 +614,12 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                     }
                     // padding item (chunk beyond n_chunks, pixel outside the image): nothing to do, pull again
                 }
-                pool_next = min(pool_end, pool_next + (unsigned)__popcll(take_mask));
+                const unsigned want = (unsigned)__popcll(take_mask), have = pool_end - pool_next;
+                if (PROFILE && want > have) clk.count(11, want - have);                // takers the pool could not serve in this round
+                pool_next = min(pool_end, pool_next + want);
+                if (want <= have) break;                                              // every taker was served (padding items: they pull again next time)
             }
+            if (PROFILE) clk.count(12, (unsigned)__popcll(__ballot(need && alive && !have_item)));     // takers left without an item in this iteration
         }
         if (!__any(alive)) break;
         clk.lap(0);
@@ -601,13 +653,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             T du = 0, dv = 0;
             if (jitter) {
                 T r1, r2;
-#ifdef RTW_PROBE_FASTDIV
-                trand(rng, r1); du = r1 * probe_rcp(w_div);
-                trand(rng, r2); dv = r2 * probe_rcp(h_div);
-#else
-                trand(rng, r1); du = r1 / w_div;
-                trand(rng, r2); dv = r2 / h_div;
-#endif
+                trand(rng, r1); du = RTW_DIV(r1, w_div);
+                trand(rng, r2); dv = RTW_DIV(r2, h_div);
             }
             const JobSlot *S = sh->slot((ref_depth & RTW_REF_MASK) >> 4, P.slot_stride);
             const unsigned px = ref_depth & 15u;
@@ -627,16 +674,12 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         T len2 = 0;
         {
             bool pending = ball || new_sample;
-#ifdef RTW_DUP_REJECT    // instruction-count probe: the rejection loop twice (the first run on a copy of the generator)
-            { Rng r2 = rng; V3<T> q2 = {0, 0, 0}; T l2 = 0; bool p2 = pending;
-              while (__any(p2)) { if (p2) { l2 = reject_trial<T>(r2, ball, q2); p2 = !(l2 <= T(1)); } }
-              __asm__ volatile("" :: "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(l2), "v"((unsigned)r2.x), "v"((unsigned)r2.y)); }
-#endif
+            RTW_PROBE_REJECT_TWICE();
             // (wave priority, Float32 matrix-pipe kernels -- see hit_world_mfma: this loop is pure VALU work, a filler like the block
             //  loop; 364.0 -> 363.0 ms)
             constexpr bool use_prio = MFMA && sizeof(T) == 4 && RTW_SCAN_PRIO != 0;
             if (use_prio) __builtin_amdgcn_s_setprio(0);
-#ifdef RTW_PROBE_REJ_CAP     // time probe (WRONG image): the loop stops after that many trials -- the upper bound of what parking the stragglers can gain
+#ifdef RTW_PROBE_REJ_CAP     // (rtw_probes.hpp)
             for (int rr = 0; rr < RTW_PROBE_REJ_CAP && pending; ++rr) {
                 len2 = reject_trial<T>(rng, ball, rp);
                 pending = !(len2 <= T(1));
@@ -670,7 +713,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
     }
 
     if (PROFILE && lane == 0) {
-        for (int k = 0; k < 8; ++k) atomicAdd(&ctr->phase[k], clk.acc[k]);
+        for (int k = 0; k < 16; ++k) atomicAdd(&ctr->phase[k], clk.acc[k]);
     }
     if (lane == 0) {
         // A global atomic is a 32-byte write at the memory side: the waves of a workgroup add up in LDS and the last one to
@@ -682,7 +725,8 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         if (__hip_atomic_fetch_add(&sh->fin_waves, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == nw - 1u) {
             atomicAdd(&ctr->segments, __hip_atomic_load(&sh->fin_segments, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             atomicAdd(&ctr->samples, __hip_atomic_load(&sh->fin_samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            // the end-of-queue drain: first wave start, last wave end, sum of the wave ends, waves by end time
+            // the end-of-queue drain (RTW_DRAIN_PROFILE only): first wave start, last wave end, sum of the wave ends, waves by end time
+            if (P.drain_profile) {
             unsigned long long t_start = ~0ull, t_end = 0ull, t_sum = 0ull;
             for (unsigned w = 0; w < nw && w < 4u; ++w) {
                 const unsigned long long a = __hip_atomic_load(&sh->t_wave[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -697,6 +741,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             for (unsigned w = 0; w < nw && w < 4u; ++w) {
                 const unsigned long long bin = (__hip_atomic_load(&sh->t_wave[4u + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - t0) / 25000ull;
                 atomicAdd(&ctr->end_hist[bin < 4095ull ? (unsigned)bin : 4095u], 1u);
+            }
             }
         }
     }

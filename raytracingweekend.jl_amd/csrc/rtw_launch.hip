@@ -2,7 +2,9 @@
 // instantiation, the persistent grid, the job shape, the per-render counters and events, and what rtw_stats() reads back.
 #include "rtw_scene_view.hpp"
 #include "rtw_kernels.hpp"
+#ifdef RTW_WITH_POOL          // `make POOL=1`: the ray-pool kernel (a measured 16 - 19 % LOSS on this chip, DESIGN_LOG R4) is not in the default library
 #include "rtw_pool.hpp"
+#endif
 
 namespace rtwh {
 
@@ -51,8 +53,7 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     using V4 = typename rtw::Vec4<T>::type;
     rtw::DevScene<T> S = dev_scene_of<T>(scene);
     // the deciding arithmetic of the ray-sphere test (include/rtw_hip.h RTW_FLAG_NUMERICS_*): a property of the render, not of the upload
-    S.numerics = (p->flags & RTW_FLAG_NUMERICS_CONTRACT) ? rtw::NUM_CONTRACT : (p->flags & RTW_FLAG_NUMERICS_REFERENCE_FMA) ? rtw::NUM_REFERENCE_FMA :
-                 (p->flags & RTW_FLAG_NUMERICS_REFERENCE_FMA2) ? rtw::NUM_REFERENCE_FMA2 : rtw::NUM_REFERENCE;
+    S.numerics = (p->flags & RTW_FLAG_NUMERICS_CONTRACT) ? rtw::NUM_CONTRACT : (p->flags & RTW_FLAG_NUMERICS_REFERENCE_FMA2) ? rtw::NUM_REFERENCE_FMA2 : rtw::NUM_REFERENCE;
 
     // persistent grid: enough 256-thread blocks to fill every CU at the kernel's occupancy
     static const bool phase_profile = aid_env("RTW_PHASE_PROFILE") != nullptr;   // debugging aid, not for timed runs
@@ -85,12 +86,15 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     // the default numerics mode of the headline variants (scene in LDS, matrix pipe): an instance with the mode fixed at compile time
     if (S.numerics == rtw::NUM_REFERENCE && lds_scene && mfma && !phase_profile)
         kern = cull ? (kern_t)rtw::trace_kernel<T, false, true, true, true, rtw::NUM_REFERENCE> : (kern_t)rtw::trace_kernel<T, false, true, false, true, rtw::NUM_REFERENCE>;
-    // The ray-pool kernel (rtw_pool.hpp; opt-in: RTW_FLAG_RAY_POOL, or RTW_POOL=1 in the environment for A/B runs): Float32 plain
-    // scans on the matrix pipe, when the pool, the rings and the scene copy fit the 160 KB of LDS of a CU (one workgroup of
-    // RTW_POOL_W waves per CU); everything else runs the lane-loop kernel above.
-    static const bool env_pool = aid_flag("RTW_POOL");
-    size_t pool_lds = 0;
+    // The ray-pool kernel (rtw_pool.hpp; opt-in: RTW_FLAG_RAY_POOL, or RTW_POOL=1 in the environment for A/B runs) exists in `make POOL=1`
+    // builds only: Float32 plain scans on the matrix pipe, when the pool, the rings and the scene copy fit the 160 KB of LDS of a CU (one
+    // workgroup of RTW_POOL_W waves per CU); everything else runs the lane-loop kernel above.  The default library refuses the flag.
+    [[maybe_unused]] size_t pool_lds = 0;
     bool pool = false;
+    int block_threads = 256;
+    int blocks_per_cu = 0;
+#ifdef RTW_WITH_POOL
+    static const bool env_pool = aid_flag("RTW_POOL");
     typedef void (*pool_kern_t)(rtw::KParams, rtw::Camera<T>, rtw::DevScene<T>, T *, rtw::DevCounters *);
     pool_kern_t pool_kern = nullptr;
     if constexpr (sizeof(T) == 4) {
@@ -99,15 +103,26 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
                cs <= RTW_POOL_MAX_CHUNK_SPP;
         pool_kern = phase_profile ? (pool_kern_t)rtw::trace_pool_kernel<T, RTW_POOL_W, RTW_POOL_R, true> : (pool_kern_t)rtw::trace_pool_kernel<T, RTW_POOL_W, RTW_POOL_R, false>;
     }
-    int block_threads = pool ? RTW_POOL_W * 64 : 256;
-    int blocks_per_cu = 0;
     if (pool) {
+        block_threads = RTW_POOL_W * 64;
         // "everything else runs the lane-loop kernel": also a device (or a runtime) that refuses this much dynamic LDS
         hipError_t e = hipFuncSetAttribute((const void *)pool_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_lds);
         if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, pool_kern, block_threads, pool_lds);
         if (e != hipSuccess || blocks_per_cu < 1) { (void)hipGetLastError(); pool = false; block_threads = 256; blocks_per_cu = 0; }
     }
-    if (!pool) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 256, lds_bytes));
+#else
+    if (p->flags & RTW_FLAG_RAY_POOL)
+        return fail(-7, "RTW_FLAG_RAY_POOL: this build of librtw_hip has no ray-pool kernel (a measured loss on MI355X; `make POOL=1` builds it in)");
+#endif
+    if (!pool) {
+        // (the runtime's answer for a (kernel, LDS size) pair does not change: asked once per device context -- 4 us per render otherwise)
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (auto &o : ctx->occupancy) if (o.first.first == (const void *)kern && o.first.second == lds_bytes) blocks_per_cu = o.second;
+        if (blocks_per_cu < 1) {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 256, lds_bytes));
+            ctx->occupancy.push_back({{(const void *)kern, lds_bytes}, blocks_per_cu});
+        }
+    }
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     long long grid = (long long)ctx->num_cus * blocks_per_cu;
     // Job size.  A job is owned by one workgroup, so its size sets the end-of-queue drain; smaller jobs also store the
@@ -117,8 +132,17 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     // (tools/gpu_drain.py): drain 4.4 / 9.7 / 30 ms of idle wave slots for 1 / 4 / 16-pixel jobs; full frame 859 / 859 /
     // 871 ms; a 1/8 shard 115.6 / 119.8 / 137.7 ms; HBM writes 148 / 72 / 45 MB per frame.
     // (Slots per workgroup: 24 / 12 / 4 -- one-pixel jobs need many slots in flight; with 6 they ran 33 % slower.)
+    // Round 6, with out-of-order job slots and static first claims (tools/gpu_small_sweep.sh, kernel us for 1 / 4 / 8 / 16 pixels):
+    //   1/8 shard of 1080p x 1000 spp (250 chunks)   51.1 / 53.0 / -- / 73.8 ms      one-pixel jobs: the shortest drain
+    //   1/8 shard of 1080p x 64 spp (64 chunks)      4.28 / 4.08 / -- / 5.22 ms      (1 pixel x 64 chunks = ONE batch per job: every batch opens a job)
+    //   320 x 180 x 64 spp (64 chunks; 11 jobs of 4 pixels per workgroup)            1008 / 838 / 1002 / 997 us
+    //   200 x 112 x 32 spp Float64 (32 chunks; 5 per workgroup)                      572 / 377 / 419 / 334 us
+    //   96 x 54 x 16 spp (16 chunks; 1 per workgroup)                                527 / 155 / 91 / 58 us
+    // -> one pixel only when its batches are many (>= 2 per job); the LARGEST jobs when a workgroup sees only a handful (a frame of
+    //    a few hundred microseconds is a latency chain per wave: the fewest job openings win).
     int job_shift = nch >= 16 ? 2 : 4;
-    if (nch >= 64 && n_local * 16 < 150 * grid) job_shift = 0;
+    if (nch >= 128 && n_local * 16 < 150 * grid) job_shift = 0;
+    else if (n_local * 16 < 8 * grid) job_shift = 4;
     // (measurement aid for A/B runs, tools/gpu_ab.sh: RTW_JOB_PIXELS = 1, 4, 8 or 16; any other value is ignored)
     static const int env_job_pixels = [] { const char *e = aid_env("RTW_JOB_PIXELS"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 4 || v == 8 || v == 16) ? v : 0; }();
     const int job_pixels = p->job_pixels ? p->job_pixels : env_job_pixels;
@@ -132,7 +156,7 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     const long long bpj = (nch + cpb - 1) / cpb;
     // (claim_job packs a queue position into 28 bits; queue 0 is the longest: every 8th tile column, or every 8th tile of a shard)
     const long long queue0_jobs = (p->shard_count == 1 ? (long long)((K.tiles_j + 7) / 8) * K.tiles_i : (n_local + 7) / 8) * (64 >> job_shift);
-    if (total_jobs >= (1ll << 31) || queue0_jobs >= (1ll << 28) || total_jobs * bpj >= (1ll << 40))
+    if (total_jobs >= (1ll << 30) || queue0_jobs >= (1ll << 28) || total_jobs * bpj >= (1ll << 40))
         return fail(-5, "render too large for one call: %lld pixel-block jobs", total_jobs);
     K.total_jobs = (unsigned)total_jobs; K.local_tiles = (unsigned)n_local; K.bpj = (unsigned)bpj; K.job_shift = (unsigned)job_shift;
     K.rows_shift = (unsigned)std::min(job_shift, 3);       // 4 x 1, 8 x 1, 8 x 2 pixels: whole column strips
@@ -142,28 +166,43 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     K.n_slots = std::min(24u, (unsigned)RTW_SLOT_BYTES / K.slot_stride);             // 24 / 12 / 7 / 4 slots of 1 / 4 / 8 / 16 pixels
     make_udiv(K.n_slots, &K.div_slots_m, &K.div_slots_s);
     make_udiv((unsigned)bpj, &K.div_bpj_m, &K.div_bpj_s);
-    const long long max_useful = pool ? (total_jobs * bpj * 64 + RTW_POOL_R - 1) / RTW_POOL_R       // one item per slot of the pool
-                                      : (total_jobs * bpj + 3) / 4;                                // one batch per wave, 4 waves per block
+    long long max_useful = (total_jobs * bpj + 3) / 4;                                             // one batch per wave, 4 waves per block
+#ifdef RTW_WITH_POOL
+    if (pool) max_useful = (total_jobs * bpj * 64 + RTW_POOL_R - 1) / RTW_POOL_R;                  // one item per slot of the pool
+#endif
     if (grid > max_useful) grid = max_useful;
+    // (measurement aid: RTW_GRID_BLOCKS caps the persistent grid -- fewer waves per SIMD, same image)
+    static const long long env_grid = aid_env("RTW_GRID_BLOCKS") ? atoll(aid_env("RTW_GRID_BLOCKS")) : 0;
+    if (env_grid > 0 && grid > env_grid) grid = env_grid;
     if (grid < 1) grid = 1;
 
     RenderRec *rec;
     if (int rc = acquire_rec(ctx.get(), &rec)) return rc;
     *rec_out = rec;
     rec->n_spheres = scene->n; rec->n_chunks = nch; rec->grid = (int)grid; rec->block = block_threads;
-    HIP_TRY(hipMemsetAsync(rec->ctr, 0, sizeof(rtw::DevCounters), stream));
-    HIP_TRY(hipMemsetAsync(&rec->ctr->t_first, 0xff, sizeof(unsigned long long), stream));
+    // the counters: queue heads + segment / sample counts (+ the phase cells) are cleared per render; the drain clocks and their 16 KB
+    // histogram only when the drain is profiled (the kernel touches them only then)
+    static const bool drain_profile = aid_env("RTW_DRAIN_PROFILE") != nullptr;
+    K.drain_profile = drain_profile ? 1 : 0;
+    rec->ctr_bytes = (drain_profile || phase_profile || pool) ? sizeof(rtw::DevCounters) : offsetof(rtw::DevCounters, t_first);    // (the ray-pool kernel keeps its stage profile / watchdog state in the histogram cells)
+    HIP_TRY(hipMemsetAsync(rec->ctr, 0, rec->ctr_bytes, stream));
+    if (drain_profile) HIP_TRY(hipMemsetAsync(&rec->ctr->t_first, 0xff, sizeof(unsigned long long), stream));
     // pixels of other shards read 0 in the full-frame layout (the sum over the shards is the image)
     if (K.out_layout == 0 && p->shard_count > 1)
         HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)p->width * p->height * 3 * sizeof(T), stream));
     HIP_TRY(hipEventRecord(rec->ev0, stream));
     if (total_jobs > 0) {
         (void)hipGetLastError();           // (hipEventQuery's hipErrorNotReady in acquire_rec must not be mistaken for a launch failure)
+#ifdef RTW_WITH_POOL
         if (pool) hipLaunchKernelGGL(pool_kern, dim3((unsigned)grid), dim3((unsigned)block_threads), pool_lds, stream, K, C, S, (T *)d_out, rec->ctr);
-        else hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, CS, (T *)d_out, rec->ctr);
+        else
+#endif
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, K, C, S, CS, (T *)d_out, rec->ctr);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(rec->ev1, stream));
+    HIP_TRY(hipMemcpyAsync(rec->h_ctr, rec->ctr, rec->ctr_bytes, hipMemcpyDeviceToHost, stream));     // (into pinned memory: truly asynchronous)
+    HIP_TRY(hipEventRecord(rec->ev2, stream));
     rec->used = true; rec->done = false;
     return 0;
 }
@@ -171,12 +210,11 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
 // wait for a record's kernel and add its counters to `agg`
 int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipEventSynchronize(r->ev1));
+    HIP_TRY(hipEventSynchronize(r->ev2));
     r->done = true;
     float k_ms = 0;
     HIP_TRY(hipEventElapsedTime(&k_ms, r->ev0, r->ev1));
-    rtw::DevCounters c;                    // (16 KB incl. the drain histogram)
-    HIP_TRY(hipMemcpy(&c, r->ctr, sizeof c, hipMemcpyDeviceToHost));
+    const rtw::DevCounters &c = *r->h_ctr;         // (the copy that followed the kernel on its stream; the drain part only with RTW_DRAIN_PROFILE)
     if (aid_env("RTW_PHASE_PROFILE") && r->block != 256) {
         const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(c.end_hist + 256);
         static const char *names[6] = {"SCAN", "LM", "END", "DIEL", "REJ", "WAIT"};
@@ -192,26 +230,16 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
         fprintf(stderr, "[rtw phase profile] wave-cycles: pull %.1f%%  sample+scatter finish %.1f%%  scan-pass1/level1 %.1f%%  extract/level2 %.1f%%  resolve %.1f%%  shade %.1f%%  (total %.3g)\n",
                 100 * c.phase[0] / tot, 100 * c.phase[1] / tot, 100 * c.phase[2] / tot, 100 * c.phase[4] / tot,
                 100 * c.phase[5] / tot, 100 * c.phase[3] / tot, tot);
+        if (c.phase[8])
+            fprintf(stderr, "[rtw phase profile] lane loop: %llu wave-iterations, lane utilisation at the scan %.2f %% (%llu lanes with a ray), %.2f %% of the iterations without any ray; "
+                            "lane-iterations lost at batch boundaries %.2f %% (pool short) + %.2f %% (no usable batch)\n", (unsigned long long)c.phase[8],
+                    100.0 * (double)c.phase[9] / (64.0 * (double)c.phase[8]), (unsigned long long)c.phase[9], 100.0 * (double)c.phase[10] / (double)c.phase[8],
+                    100.0 * (double)c.phase[11] / (64.0 * (double)c.phase[8]), 100.0 * (double)c.phase[12] / (64.0 * (double)c.phase[8]));
         if (c.phase[7])
             fprintf(stderr, "[rtw phase profile] matrix-pipe scan: %.1f%% of the (wave, block of 32 spheres) evaluations found no candidate in any lane (%llu of %llu)\n",
                     100.0 * (double)c.phase[6] / (double)c.phase[7], (unsigned long long)c.phase[6], (unsigned long long)c.phase[7]);
     }
-#ifdef RTW_CAND_HIST
-    {
-        static std::vector<unsigned> hh(8192);
-        HIP_TRY(hipMemcpyFromSymbol(hh.data(), HIP_SYMBOL(rtw::g_cand_hist), 8192 * sizeof(unsigned)));
-        unsigned long long fl = 0, tr = 0;
-        for (int i = 0; i < 4096; ++i) { fl += hh[2 * i]; tr += hh[2 * i + 1]; }
-        fprintf(stderr, "[rtw cand hist] cumulative: %llu candidates with discriminant < 0 (filter margin), %llu with discriminant >= 0; per segment %.4f / %.4f\n", fl, tr,
-                (double)fl / (double)std::max<unsigned long long>(1, c.segments), (double)tr / (double)std::max<unsigned long long>(1, c.segments));
-        fprintf(stderr, "[rtw cand hist] first spheres (false, true):");
-        for (int i = 0; i < 8; ++i) fprintf(stderr, " %d:(%u,%u)", i, hh[2 * i], hh[2 * i + 1]);
-        fprintf(stderr, " ... last:");
-        for (int i = std::max(0, r->n_spheres - 4); i < r->n_spheres; ++i) fprintf(stderr, " %d:(%u,%u)", i, hh[2 * i], hh[2 * i + 1]);
-        fprintf(stderr, "\n");
-    }
-#endif
-    if (c.end_hist[0] == 0xdeadbeefu) {        // (RTW_POOL_WATCHDOG builds: the pool kernel gave up; its state)
+    if (r->ctr_bytes == sizeof(rtw::DevCounters) && c.end_hist[0] == 0xdeadbeefu) {        // (RTW_POOL_WATCHDOG builds: the pool kernel gave up; its state)
         fprintf(stderr, "[rtw pool watchdog]");
         for (int k = 1; k <= 113; ++k) fprintf(stderr, " %u", c.end_hist[k]);
         fprintf(stderr, "\n");

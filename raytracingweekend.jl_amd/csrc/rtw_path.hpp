@@ -29,6 +29,7 @@ template <typename T> __device__ __forceinline__ V3<T> vneg(V3<T> a) { return {-
 // StaticArrays dot, length 3: (a1*b1 + a2*b2) + a3*b3
 template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 // StaticArrays normalize(v) = inv(norm(v)) * v
+#include "rtw_probes.hpp"
 #ifdef RTW_PROBE_FASTDIV   // time probe (WRONG image): approximate reciprocal square root / reciprocal instead of the IEEE sqrt and divisions
 __device__ __forceinline__ float probe_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ double probe_rsq(double x) { return 1.0 / __builtin_sqrt(x); }
@@ -36,11 +37,7 @@ __device__ __forceinline__ float probe_rcp(float x) { return __builtin_amdgcn_rc
 __device__ __forceinline__ double probe_rcp(double x) { return 1.0 / x; }
 #endif
 template <typename T> __device__ __forceinline__ V3<T> normalize(V3<T> a) {
-#ifdef RTW_PROBE_FASTDIV
-    T inv = probe_rsq(dot(a, a));
-#else
-    T inv = T(1) / t_sqrt(dot(a, a));
-#endif
+    T inv = RTW_RSQRT(dot(a, a));
     return vscale(inv, a);
 }
 // src/vec.jl:19-20: compared against the Float64 literal 1e-5
@@ -124,11 +121,7 @@ template <typename T> __device__ __forceinline__ T reject_trial(Rng &r, bool bal
 }
 // normalize(p) when p.p is already known: StaticArrays' inv(norm(p)) * p with norm = sqrt(p.p)
 template <typename T> __device__ __forceinline__ V3<T> normalize_len2(V3<T> p, T len2) {
-#ifdef RTW_PROBE_FASTDIV
-    return vscale(probe_rsq(len2), p);
-#else
-    return vscale(T(1) / t_sqrt(len2), p);
-#endif
+    return vscale(RTW_RSQRT(len2), p);
 }
 // src/rand.jl:15-22,29: rejection in the unit ball (x,y,z order, boundary inclusive), normalised
 template <typename T> __device__ __forceinline__ V3<T> random_vec3_on_sphere(Rng &r) {
@@ -149,12 +142,12 @@ template <typename T> __device__ __forceinline__ void random_vec2_in_disk(Rng &r
 //   NUM_REFERENCE (default)  as the reference evaluates it: `oc . r.dir` and `oc . oc` are StaticArrays' dot -- a callee that
 //                            @fastmath does not rewrite: (x1 y1 + x2 y2) + x3 y3, no FMA --, then  c = oc.oc - r^2  and
 //                            disc = half_b^2 - c  with one rounding each
-//   NUM_REFERENCE_FMA        the same with the last step contracted: disc = fma(half_b, half_b, -c)
-//   NUM_REFERENCE_FMA2       ... and c = fma(-r, r, oc.oc) as well: what LLVM makes of src/hit.jl:17-18 on an FMA target when BOTH squares carry
+//   NUM_REFERENCE_FMA2       the un-fused dots with both squares contracted, disc = fma(half_b, half_b, -c) and c = fma(-r, r, oc.oc): what LLVM makes of src/hit.jl:17-18 on an FMA target when BOTH squares carry
 //                            fast-math flags (tools/llvm_fastmath_check: with the flag-less llvm.powi that Julia's pow_fast emits, neither is fused)
 //   NUM_CONTRACT             rounds 1 - 4: half_b, r^2 - |oc|^2 and disc as three FMA chains
 // (this file is compiled with -ffp-contract=off: the un-fused forms stay un-fused).
-enum { NUM_REFERENCE = 0, NUM_CONTRACT = 1, NUM_REFERENCE_FMA = 2, NUM_REFERENCE_FMA2 = 3 };
+// (code 2 was NUM_REFERENCE_FMA -- only the last step contracted -- until ABI 3: removed, no compiler was found to emit it)
+enum { NUM_REFERENCE = 0, NUM_CONTRACT = 1, NUM_REFERENCE_FMA2 = 3 };
 template <int N> struct NumTag { static constexpr int value = N; };
 // `r`: the sphere's radius itself -- read only by NUM_REFERENCE_FMA2 (c = fma(-r, r, oc.oc): the un-rounded square)
 template <typename T, int NUM>
@@ -178,7 +171,6 @@ template <typename T>
 __device__ __forceinline__ void sphere_disc(int num, T cx, T cy, T cz, T r2, T r, V3<T> o, V3<T> d, T &half_b, T &disc) {
     if (num == NUM_REFERENCE) sphere_disc_n<T, NUM_REFERENCE>(cx, cy, cz, r2, r, o, d, half_b, disc);
     else if (num == NUM_CONTRACT) sphere_disc_n<T, NUM_CONTRACT>(cx, cy, cz, r2, r, o, d, half_b, disc);
-    else if (num == NUM_REFERENCE_FMA) sphere_disc_n<T, NUM_REFERENCE_FMA>(cx, cy, cz, r2, r, o, d, half_b, disc);
     else sphere_disc_n<T, NUM_REFERENCE_FMA2>(cx, cy, cz, r2, r, o, d, half_b, disc);
 }
 // src/hit.jl:19-29: root selection against [tmin, closest]; returns true and the root on a hit
@@ -202,12 +194,7 @@ __device__ __forceinline__ void make_hitrec(V3<T> c, T r, V3<T> o, V3<T> d, T t,
     rec.t = t;
     rec.p = vadd(o, vscale(t, d));
     V3<T> pc = vsub(rec.p, c);
-#ifdef RTW_PROBE_FASTDIV
-    const T ir_ = probe_rcp(r);
-    V3<T> n_out = {pc.x * ir_, pc.y * ir_, pc.z * ir_};
-#else
-    V3<T> n_out = {pc.x / r, pc.y / r, pc.z / r};
-#endif
+    V3<T> n_out = {RTW_DIV(pc.x, r), RTW_DIV(pc.y, r), RTW_DIV(pc.z, r)};
     rec.front = dot(d, n_out) < T(0);
     rec.n = rec.front ? n_out : vneg(n_out);
 }

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
     ws.pairs = reinterpret_cast<unsigned *>(smem) + wv * RTW_POOL_PAIR_CAP;
     ws.keys = reinterpret_cast<unsigned long long *>(smem + pairs_bytes) + wv * 64;
     ws.kidx = reinterpret_cast<unsigned *>(smem + pairs_bytes + (size_t)W * 64 * 8) + wv * 64;
-    ws.cap = RTW_POOL_PAIR_CAP;
+    ws.cap = RTW_POOL_PAIR_CAP / 2;          // (entries of two words)
 
     // ---- set-up: every slot starts in END, "nothing to add, needs an item" ----
     for (unsigned i = threadIdx.x; i < PQ_COUNT * RTW_POOL_RING; i += W * 64) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
         sh->fin_waves = 0u; sh->fin_segments = 0ull; sh->fin_samples = 0ull;
         sh->disp.lock = 0u; sh->disp.next = 0u; sh->disp.end = 0u; sh->disp.slot = 0u; sh->disp.b = 0u;
         sh->disp.have_job = 0u; sh->disp.valid = 0ull;
-        sh->jobs.jc = 0ull; sh->jobs.jc_lock = 0u; sh->jobs.queue_off = 0u; sh->jobs.last_g = 0u;
+        sh->jobs.jc = 0ull; sh->jobs.jc_lock = 0u; sh->jobs.queue_off = 0u; sh->jobs.last_g = 0u; sh->jobs.static_used = 0u;
         sh->cam = cam_arg; sh->P = P_arg;
     }
     if (PROFILE && threadIdx.x < 32) sh->prof[threadIdx.x] = 0ull;

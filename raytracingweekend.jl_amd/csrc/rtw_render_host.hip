@@ -274,7 +274,10 @@ int render_host(const SceneT *scene, const CamT *cam, const rtw_params *p, T *ou
     if (rccl_use.owns_lock()) rccl_use.unlock();           // the communicators are free for the next render of this device list
     rtw_stats_t &a = g_last.agg;                       // sums over the devices; times: the maximum
     for (int r = 0; r < N; ++r) {
-        if (!recs[r]) continue;
+        if (!recs[r]) {                                   // a shard that owns no tile (a tiny frame on many devices): launched nothing --
+            if (!rc) g_last.per_device.emplace_back(L[r].hc->device, 0.0);     // still one entry per shard, in shard order (include/rtw_hip.h)
+            continue;
+        }
         rtw_stats_t st;
         memset(&st, 0, sizeof st);
         if (!rc) rc = resolve_rec(recs[r], &st);

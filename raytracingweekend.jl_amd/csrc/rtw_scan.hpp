@@ -108,7 +108,6 @@ __device__ __forceinline__ void resolve_candidates(int num, SRC src, const typen
                                                    const unsigned short *list, int cnt) {
     if (num == NUM_REFERENCE) resolve_candidates_n<T, STRIDE, NUM_REFERENCE>(src, rad, o, d, tmin, closest, idx, list, cnt);
     else if (num == NUM_CONTRACT) resolve_candidates_n<T, STRIDE, NUM_CONTRACT>(src, rad, o, d, tmin, closest, idx, list, cnt);
-    else if (num == NUM_REFERENCE_FMA) resolve_candidates_n<T, STRIDE, NUM_REFERENCE_FMA>(src, rad, o, d, tmin, closest, idx, list, cnt);
     else resolve_candidates_n<T, STRIDE, NUM_REFERENCE_FMA2>(src, rad, o, d, tmin, closest, idx, list, cnt);
 }
 
@@ -166,7 +165,7 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
         } else {
             T hb, disc;
             if constexpr (decltype(tag)::value == NUM_REFERENCE_FMA2) {
-                // The scalar stream carries r^2, not r: pass 1 evaluates the reference_fma form and adds a margin that covers what the
+                // The scalar stream carries r^2, not r: pass 1 evaluates the form with only the last step contracted and adds a margin that covers what the
                 // un-rounded square can change -- the two values of c differ by <= u r^2 (the rounding of r r) + 2 u (oc.oc + r^2) (their
                 // own roundings), the two final fmas by <= 2 u (half_b^2 + oc.oc + r^2): < 8 u (oc.oc + r^2) = 2^-21 (oc.oc + r^2) in all.
                 // A superset is all pass 1 owes; pass 2 decides with the radius itself.
@@ -245,14 +244,8 @@ __device__ __forceinline__ int hit_world(const DevScene<T> &w, SRC src, V3<T> o,
     if constexpr (F64) scan(NumTag<NUM_REFERENCE>{});        // (the binary32 filter does not depend on the mode)
     else if (w.numerics == NUM_REFERENCE) scan(NumTag<NUM_REFERENCE>{});
     else if (w.numerics == NUM_CONTRACT) scan(NumTag<NUM_CONTRACT>{});
-    else if (w.numerics == NUM_REFERENCE_FMA) scan(NumTag<NUM_REFERENCE_FMA>{});
     else scan(NumTag<NUM_REFERENCE_FMA2>{});
     resolve_candidates<T, STRIDE>(w.numerics, src, w.mat0, o, d, tmin, closest, idx, list, cnt);
-#ifdef RTW_DUP_RESOLVE   // instruction-count probe: the final resolve twice (idempotent: same winner)
-    { T c2 = tmax; int i2 = -1; __asm__ volatile("" : "+v"(c2), "+v"(i2));
-      resolve_candidates<T, STRIDE>(w.numerics, src, w.mat0, o, d, tmin, c2, i2, list, cnt);
-      __asm__ volatile("" :: "v"(c2), "v"(i2)); }
-#endif
     clk.lap(5);
     t_hit = closest;
     return idx;

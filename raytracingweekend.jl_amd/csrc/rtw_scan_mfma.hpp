@@ -3,6 +3,7 @@
 #pragma once
 #include "rtw_scan.hpp"
 #include "rtw_cull_tables.hpp"
+#include "rtw_probes.hpp"
 
 namespace rtw {
 
@@ -70,7 +71,7 @@ namespace rtw {
 // else the far root if that is -- and the LAST sphere among exact ties; a sphere whose near root exceeds the running
 // closest cannot win with its far root either.  That is the minimum of the 64-bit keys (root bits, ~sphere): one LDS
 // atomic min per accepted candidate (Float64: min on the root bits, then max on the index among the candidates equal to it).
-#define RTW_PAIR_CAP 512     // (owner, sphere) pairs per wave; a full list is resolved early
+#define RTW_PAIR_CAP 512     // 32-bit words of a wave's candidate list: 256 entries of (bits, lane << 16 | block << 5); a full list is resolved early
 typedef _Float16 rtw_h8 __attribute__((ext_vector_type(8)));
 typedef float rtw_f16v __attribute__((ext_vector_type(16)));
 
@@ -105,10 +106,10 @@ struct MfmaCull {
 };
 
 struct WaveScratch {
-    unsigned *pairs;              // RTW_PAIR_CAP entries: recording lane << 16 | block << 5 | bit (see resolve_pairs)
+    unsigned *pairs;              // the wave's candidate list, 8-byte aligned: entries of two words (see resolve_pairs)
     unsigned long long *keys;     // 64 entries: Float32 (root bits << 32 | ~sphere); Float64 root bits
     unsigned *kidx;               // Float64 only: 64 entries, sphere + 1
-    unsigned cap = RTW_PAIR_CAP;  // entries in `pairs` (wave-uniform; the ray-pool kernel gives a wave 256)
+    unsigned cap = RTW_PAIR_CAP / 2;  // ENTRIES in `pairs` (wave-uniform; the ray-pool kernel gives a wave 128)
 };
 
 // x = p1 + p2 with p1 = RN16(x), p2 = RN16(x - p1); returns p1 | p2 << 16
@@ -116,15 +117,9 @@ struct WaveScratch {
 // (exact in binary32: p1 is x rounded to 11 bits) and rounds it once into the high half -- the same bits as the five instructions the
 // compiler makes of the C form (convert, convert back, subtract, convert, pack): 11 splits per scan, 34 VALU instructions fewer.
 __device__ __forceinline__ unsigned split_f16(float x) {
-#ifdef RTW_SPLIT_C_FORM
-    const _Float16 p1 = (_Float16)x;
-    const _Float16 p2 = (_Float16)(x - (float)p1);
-    return (unsigned)__builtin_bit_cast(unsigned short, p1) | ((unsigned)__builtin_bit_cast(unsigned short, p2) << 16);
-#else
     unsigned w;
     __asm__("v_cvt_f16_f32_e32 %0, %1\n\tv_fma_mixhi_f16 %0, %1, 1.0, -%0 op_sel_hi:[0,0,1]" : "=&v"(w) : "v"(x));
     return w;
-#endif
 }
 __device__ __forceinline__ float lane_get(float v, unsigned src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
@@ -136,82 +131,61 @@ __device__ __forceinline__ double lane_get(double v, unsigned src_lane) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// Pass 1 flags GROUPS of RTW_SCAN_GROUP spheres (consecutive result registers of one lane = consecutive spheres): the sign
-// bits of a group's filter values are ANDed with fast-class bit operations (v_bitop3_b32 / v_and_b32: 2.4 cycles) and only
-// the group's bit goes through the slow-class v_alignbit_b32 (4.3 cycles) -- 16 + 8 instead of 32 instructions per block of
-// 32 spheres; pass 2 applies the exact test to every member of a flagged group.  1 (default): one sphere per list entry.
-// Measured (1080p x 1000 spp Float32, same box, with the wave-level early-out): single spheres 370.9 ms, groups of 2 380.5,
-// of 4 388.0 -- pass 2 pays one exact test (sqrt, root selection, LDS atomic) per member of a flagged group, more than the
-// alignbits saved.  Kept for A/B runs.
-#ifndef RTW_SCAN_GROUP
-#define RTW_SCAN_GROUP 1
-#endif
-static_assert(RTW_SCAN_GROUP == 1 || RTW_SCAN_GROUP == 2 || RTW_SCAN_GROUP == 4, "groups of 1, 2 or 4 result registers");
-#ifndef RTW_SCAN_CMP
-#define RTW_SCAN_CMP 0       // 1: sign collection by v_cmp -> SGPR lane masks instead of v_alignbit + extraction loop (experiment, rejected)
-#endif
+// (Rejected and removed in round 6, in git history: flagging GROUPS of 2 / 4 spheres per list entry -- 380.5 / 388.0 against 370.9 ms, pass 2 pays
+// one exact test per member --, and collecting the signs by v_cmp into SGPR lane masks -- +4.7 %.)
 #ifndef RTW_SCAN_SKIP
 #define RTW_SCAN_SKIP 1      // wave-level early-out per half block (hit_world_mfma): 372.2 vs 376.3 ms.  (Left to the compiler it is
                              // if-converted -- both sides executed -- and gains nothing: the sign collection's side is fenced by an asm.)
 #endif
 
-#ifdef RTW_CAND_HIST     // debug build: candidates of the filter per sphere, [2 i] = flagged but contract discriminant < 0, [2 i + 1] = discriminant >= 0
-__device__ unsigned g_cand_hist[8192];
-#endif
 // Walk n entries of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
 struct NoOrig {};
 template <typename T, bool WITH_R, typename SRC, typename ORIG = NoOrig>
 __device__ __forceinline__ void resolve_pairs_impl(int num, SRC src, [[maybe_unused]] const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
     constexpr bool CULLED = !__is_same(ORIG, NoOrig);      // device order != the caller's order: ties go by orig[], the key carries both
-    constexpr unsigned G = RTW_SCAN_GROUP;
     using V4 = typename Vec4<T>::type;
     __builtin_amdgcn_wave_barrier();
+    const uint2 *list = reinterpret_cast<const uint2 *>(ws.pairs);
     for (unsigned p0 = 0; p0 < n; p0 += 64u) {
         const unsigned p = p0 + lane;
-        const bool valid = p < n;
-        const unsigned e = ws.pairs[valid ? p : 0u];
-        // entry = recording lane (H, j) << 16 | block << 5 | b.   G = 1: b = half << 4 | result register: ray j + 32 (b >> 4), sphere
-        // 32 block + 16 H + (b & 15).   G = 2 / 4: b = half << (3 / 2) | group: ray j + 32 half, spheres 32 block + 16 H + G group + 0..G-1
-        unsigned owner, sph0;
-        if constexpr (G == 1) { owner = ((e >> 16) & 31u) + ((e & 16u) << 1); sph0 = (e & 0xffefu) + ((e >> 17) & 16u); }
-        else if constexpr (G == 2) { owner = ((e >> 16) & 31u) + ((e & 8u) << 2); sph0 = (e & 0xffe0u) + ((e >> 17) & 16u) + ((e & 7u) << 1); }
-        else { owner = ((e >> 16) & 31u) + ((e & 4u) << 3); sph0 = (e & 0xffe0u) + ((e >> 17) & 16u) + ((e & 3u) << 2); }
+        const uint2 e = list[p < n ? p : 0u];
+        // entry = (x: the recording lane's candidate bits of one block, bit 31 - b for b = half << 4 | result register,
+        //          y: recording lane (H, j) << 16 | block << 5): ray j + 32 (b >> 4), sphere 32 block + 16 H + (b & 15).
+        // A lane walks the bits of its entry; two bits are common (lanes j and j + 32 of a wave start as two chunks of one pixel: both
+        // halves see the same sphere), so the walk is the second "round" that a list of single candidates needed anyway.
+        unsigned m = p < n ? e.x : 0u;
+        const unsigned code = e.y;
+        while (__any(m != 0u)) {
+        const bool valid = m != 0u;
+        const unsigned b = 31u - (unsigned)__builtin_ctz(m | 0x80000000u);      // (a lane without a bit left: b = 0 of its entry -- a valid address, result unused)
+        m &= m - 1u;
+        const unsigned owner = ((code >> 16) & 31u) + ((b & 16u) << 1), sph = (code & 0xffe0u) + ((code >> 17) & 16u) + (b & 15u);
         const V3<T> po = {lane_get(o.x, owner), lane_get(o.y, owner), lane_get(o.z, owner)};
         const V3<T> pd = {lane_get(d.x, owner), lane_get(d.y, owner), lane_get(d.z, owner)};
-        V4 sg[G];
-#pragma unroll
-        for (unsigned m = 0; m < G; ++m) sg[m] = src[sph0 + m];
-#pragma unroll
-        for (unsigned m = 0; m < G; ++m) {
-            const unsigned sph = sph0 + m;
-            const V4 s = sg[m];
-            T hb, disc, root = 0;
-            if constexpr (WITH_R) sphere_disc_n<T, NUM_REFERENCE_FMA2>(s.x, s.y, s.z, s.w, rad[sph].x, po, pd, hb, disc);   // (mat0: the radius itself; the LDS copy holds r^2)
-            else sphere_disc<T>(num, s.x, s.y, s.z, s.w, T(0), po, pd, hb, disc);
-#ifdef RTW_CAND_HIST
-            if (valid && sph < 4096u) atomicAdd(&g_cand_hist[2u * sph + (disc < T(0) ? 0u : 1u)], 1u);
-#endif
-            if (G > 1 && !__any(valid && !(disc < T(0)))) continue;           // no entry has a candidate at this position
-            const bool hit = valid && sphere_root<T>(hb, disc, tmin, (T)__builtin_huge_val(), root);
-            unsigned tie = sph;                                  // larger = later in the caller's list
-            if constexpr (CULLED) tie = ((unsigned)orig[sph] << 16) | sph;
-            if constexpr (sizeof(T) == 4) {
-                if (hit) {
-                    const unsigned low = CULLED ? ((0xffffu - (tie >> 16)) << 16) | (tie & 0xffffu) : 0xffffffffu - tie;
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(root) << 32) | (unsigned long long)low;
-                    __hip_atomic_fetch_min(&ws.keys[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            } else {
-                const unsigned long long tb = (unsigned long long)__double_as_longlong(root);
-                unsigned long long old = 0ull;
-                if (hit) old = __hip_atomic_fetch_min(&ws.keys[owner], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __builtin_amdgcn_wave_barrier();
-                const unsigned long long cur = ws.keys[owner];
-                if (hit && tb == cur && old > tb) ws.kidx[owner] = 0u;              // the candidate that lowered the minimum to its final value of this step
-                __builtin_amdgcn_wave_barrier();
-                if (hit && tb == cur) __hip_atomic_fetch_max(&ws.kidx[owner], tie + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __builtin_amdgcn_wave_barrier();
+        const V4 s = src[sph];
+        T hb, disc, root = 0;
+        if constexpr (WITH_R) sphere_disc_n<T, NUM_REFERENCE_FMA2>(s.x, s.y, s.z, s.w, rad[sph].x, po, pd, hb, disc);   // (mat0: the radius itself; the LDS copy holds r^2)
+        else sphere_disc<T>(num, s.x, s.y, s.z, s.w, T(0), po, pd, hb, disc);
+        const bool hit = valid && sphere_root<T>(hb, disc, tmin, (T)__builtin_huge_val(), root);
+        unsigned tie = sph;                                  // larger = later in the caller's list
+        if constexpr (CULLED) tie = ((unsigned)orig[sph] << 16) | sph;
+        if constexpr (sizeof(T) == 4) {
+            if (hit) {
+                const unsigned low = CULLED ? ((0xffffu - (tie >> 16)) << 16) | (tie & 0xffffu) : 0xffffffffu - tie;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(root) << 32) | (unsigned long long)low;
+                __hip_atomic_fetch_min(&ws.keys[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+        } else {
+            const unsigned long long tb = (unsigned long long)__double_as_longlong(root);
+            unsigned long long old = 0ull;
+            if (hit) old = __hip_atomic_fetch_min(&ws.keys[owner], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long cur = ws.keys[owner];
+            if (hit && tb == cur && old > tb) ws.kidx[owner] = 0u;              // the candidate that lowered the minimum to its final value of this step
+            __builtin_amdgcn_wave_barrier();
+            if (hit && tb == cur) __hip_atomic_fetch_max(&ws.kidx[owner], tie + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+        }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -359,35 +333,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         const auto sw = __builtin_amdgcn_permlane32_swap(g0[k], g1[k], false, false);
         h0[k] = sw[0]; h1[k] = sw[1];
     }
-#ifdef RTW_DUP_OPERANDS   // time probe: the ray-operand build (features, f16 splits, word assembly, lane exchange) a second time, same result
-    {
-        float ox2 = ox, oy2 = oy, oz2 = oz, dx2_ = dx, dy2_ = dy, dz2_ = dz;
-        __asm__ volatile("" : "+v"(ox2), "+v"(oy2), "+v"(oz2), "+v"(dx2_), "+v"(dy2_), "+v"(dz2_));
-        const float q_ = __builtin_fmaf(oz2, dz2_, __builtin_fmaf(oy2, dy2_, ox2 * dx2_));
-        const float oo_ = __builtin_fmaf(oz2, oz2, __builtin_fmaf(oy2, oy2, ox2 * ox2));
-        const float o1_ = (__builtin_fabsf(ox2) + __builtin_fabsf(oy2)) + __builtin_fabsf(oz2);
-        const float oop_ = __builtin_fmaf(oo_, w.mf_oo_keep, -(w.mf_o1_coef * o1_));
-        const float tq_ = w.mf_sigma2 * __builtin_fmaf(q_, q_, -oop_);
-        const float fp_[3] = {__builtin_fmaf(-q_, dx2_, ox2) * zs2, __builtin_fmaf(-q_, dy2_, oy2) * zs2, __builtin_fmaf(-q_, dz2_, oz2) * zs2};
-        const float ax = dx2_ * z2, ay = dy2_ * z2, az = dz2_ * z2;
-        const float fq_[6] = {ax * dx2_, ay * dy2_, az * dz2_, (ax + ax) * dy2_, (ax + ax) * dz2_, (ay + ay) * dz2_};
-        unsigned sq_[6], sp_[3];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sq_[k] = split_f16(fq_[k]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) sp_[k] = split_f16(fp_[k]);
-        const float tx_ = ok ? tq_ : tx;
-        const _Float16 t1_ = (_Float16)(tx_ * (1.0f / 32768.0f));
-        const unsigned x23_ = split_f16((tx_ - 32768.0f * (float)t1_) * (1.0f / 16.0f));
-        const unsigned a0[8] = {dup(sq_[0]), cat(sq_[0], sq_[1]), sq_[1], dup(sq_[2]), sq_[5], dup(sp_[0]), cat(sp_[0], sp_[1]), sp_[1]};
-        const unsigned a1[8] = {cat(sq_[2], sq_[3]), sq_[3], dup(sq_[4]), cat(sq_[4], sq_[5]), dup(sp_[2]), cat(sp_[2], sb), ss | ((unsigned)__builtin_bit_cast(unsigned short, t1_) << 16), x23_};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const auto sw2 = __builtin_amdgcn_permlane32_swap(a0[k], a1[k], false, false);
-            __asm__ volatile("" :: "v"(sw2[0]), "v"(sw2[1]));
-        }
-    }
-#endif
+    RTW_PROBE_OPERANDS_TWICE();
     rtw_h8 B1[2], B2[2];
     {
         const uint4 q10 = {h0[0], h0[1], h0[2], h0[3]}, q11 = {h1[0], h1[1], h1[2], h1[3]};
@@ -471,21 +417,8 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         bool any_cand = false;                               // (wave-uniform)
         const rtw_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         auto eval = [&](const rtw_f16v &Wv) {
-            if constexpr (RTW_SCAN_GROUP == 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]), 31);
-            } else if constexpr (RTW_SCAN_GROUP == 2) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]) & __float_as_uint(Wv[r + 1]), 31);
-            } else {
-                // sign of (a & b & c & d) is set iff all four filter values are negative: no member is a candidate
-#pragma unroll
-                for (int r = 0; r < 16; r += 4) {
-                    const unsigned g = __builtin_amdgcn_bitop3_b32(__float_as_uint(Wv[r]), __float_as_uint(Wv[r + 1]), __float_as_uint(Wv[r + 2]), 0x80) &
-                                       __float_as_uint(Wv[r + 3]);
-                    mask = __builtin_amdgcn_alignbit(mask, g, 31);
-                }
-            }
+            for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]), 31);
         };
         // Half of the (wave, block) evaluations find no candidate in ANY lane (rays of a wave are neighbours): the sign bits of
         // a half block's 16 filter values are ANDed first (8 FMA-class v_bitop3_b32 / v_and_b32) and the 16 slow-class
@@ -497,65 +430,21 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             t &= __float_as_uint(Wv[15]);
             return !__any((int)t >= 0);
         };
-#if RTW_SCAN_CMP
-        // Experiment: one v_cmp_ge_f32 per result register -> a 64-bit lane mask in SGPRs; a non-empty mask
-        // records its lanes' candidates at once (entry = recording lane << 16 | block << 5 | half << 4 | register), no per-lane mask
-        // word, no extraction loop.  Measured: see DESIGN.md section 6.3.
-        auto record_cmp = [&](const rtw_f16v &Wv, unsigned half16, int blk_) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned long long cm = __ballot(!(Wv[r] < 0.0f));
-                if (cm) {
-                    if (total + 64u > ws.cap) { resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig); total = 0; }
-                    if (!(Wv[r] < 0.0f))
-                        ws.pairs[__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, total))] = lane_const + (unsigned)blk_ * 32u + half16 + (unsigned)r;
-                    total += (unsigned)__popcll(cm);
-                }
-            }
-        };
-#endif
-        // the filter values of one half block (32 spheres x 32 rays): two chained MFMAs.  Time probes (tools/gpu_probe_phases.sh):
-        // -DRTW_DUP_MFMA=k executes the pair k more times (same result); -DRTW_PROBE_NO_MFMA replaces it by a constant "no candidate"
-        // (WRONG image: only the in-lane huge spheres are ever hit -- what the kernel costs per wave-segment WITHOUT the matrix pipe).
+        // the filter values of one half block (32 spheres x 32 rays): two chained MFMAs (rtw_probes.hpp: time probes that repeat / replace them)
         auto filter_pair = [&](const uint4 &a1, const uint4 &a2, const rtw_h8 &b1, const rtw_h8 &b2) -> rtw_f16v {
-#ifdef RTW_PROBE_NO_MFMA
-            rtw_f16v Wn = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-            const uint4 u1 = __builtin_bit_cast(uint4, b1), u2 = __builtin_bit_cast(uint4, b2);
-            __asm__ volatile("" :: "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w), "v"(a2.x), "v"(a2.y), "v"(a2.z), "v"(a2.w));   // (the operands stay live: the loads
-            __asm__ volatile("" :: "v"(u1.x), "v"(u1.y), "v"(u1.z), "v"(u1.w), "v"(u2.x), "v"(u2.y), "v"(u2.z), "v"(u2.w));   //  and the ray operands are still made)
-            __asm__ volatile("" : "+v"(Wn));
-            return Wn;
-#else
+            RTW_PROBE_FILTER_PAIR_REPLACED(a1, a2, b1, b2);
             rtw_f16v Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a1), b1, zero, 0, 0, 0);
             Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a2), b2, Wp, 0, 0, 0);
-#ifdef RTW_DUP_MFMA
-#pragma unroll
-            for (int rep = 0; rep < (RTW_DUP_MFMA + 0 > 0 ? RTW_DUP_MFMA + 0 : 1); ++rep) {
-                // (the repeated pair takes its sphere operand through an opaque copy and starts from the previous result x 0: left
-                //  as the same expression it is merged with the first pair -- rounds 3 and 4 measured 16 register copies, not MFMAs)
-                uint4 a1c = a1;
-                __asm__ volatile("" : "+v"(a1c.x), "+v"(a1c.y), "+v"(a1c.z), "+v"(a1c.w));
-                __asm__ volatile("" : "+v"(Wp));
-                Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a1c), b1, zero, 0, 0, 0);
-                Wp = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rtw_h8, a2), b2, Wp, 0, 0, 0);
-            }
-#endif
+            RTW_PROBE_FILTER_PAIR_AGAIN(Wp, a1, a2, b1, b2);
             return Wp;
-#endif
         };
-        constexpr unsigned HB = 16u / RTW_SCAN_GROUP;       // mask bits per half block
+        constexpr unsigned HB = 16u;                          // mask bits per half block
         {
             rtw_f16v Wv = zero;
             if (!CULLED || do_half0) Wv = filter_pair(A1, A2, B1[0], B2[0]);
-#ifdef RTW_DUP_EVAL      // time probe: the sign collection twice
-            { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
-#endif
-#if RTW_SCAN_CMP
-            if ((!CULLED || do_half0) && !(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 0u, cur); }
-#else
+            RTW_PROBE_EVAL_TWICE(Wv);
             if ((CULLED && !do_half0) || (RTW_SCAN_SKIP && none(Wv))) mask = (1u << HB) - 1u;          // all negative
             else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }      // (the asm keeps it a real branch: no if-conversion)
-#endif
         }
         {
             // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
@@ -565,72 +454,43 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             __builtin_amdgcn_sched_barrier(0);
             A1 = pa[blk * 128]; A2 = pa[blk * 128 + 64];
             __builtin_amdgcn_sched_barrier(0);
-#ifdef RTW_DUP_EVAL
-            { unsigned keep = mask; eval(Wv); __asm__ volatile("" :: "v"(mask)); mask = keep; __asm__ volatile("" : "+v"(Wv)); }   // (no CSE with the real one)
-#endif
-#if RTW_SCAN_CMP
-            if ((!CULLED || do_half1) && !(RTW_SCAN_SKIP && none(Wv))) { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); record_cmp(Wv, 16u, cur); }
-#else
+            RTW_PROBE_EVAL_TWICE(Wv);
             if ((CULLED && !do_half1) || (RTW_SCAN_SKIP && none(Wv))) mask = (mask << HB) | ((1u << HB) - 1u);
             else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }
-#endif
         }
-#if RTW_SCAN_CMP
-        clk.lap(2);
-        continue;            // (the candidates of this block are already in the list)
-#endif
         clk.lap(2);
         if (RTW_SCAN_SKIP && !any_cand) {                    // no lane has a candidate in this block: nothing to extract
             if constexpr (!CULLED) { clk.count(7, 1u); clk.count(6, 1u); }
             continue;
         }
-        constexpr unsigned NB = 32u / RTW_SCAN_GROUP;     // list bits per block: bit NB - 1 - b, b = half wave << (4 | 2) | result register / group
+        // (the block's mask: bit 31 - b, b = half wave << 4 | result register)
         unsigned m = ~mask;
-        if constexpr (NB < 32u) m &= (1u << NB) - 1u;
         if constexpr (!CULLED) {                          // (phase-profile build only: blocks, and blocks without any candidate)
             clk.count(7, 1u);
             if (!__any(m != 0u)) clk.count(6, 1u);
         }
-        const unsigned code0 = lane_const + (unsigned)cur * 32u + (NB - 1u);      // entry = recording lane << 16 | block << 5 | b
-#ifdef RTW_DUP_EXTRACT   // instruction/time probe: the extraction loop twice (the first run writes the same entries)
-        { unsigned m2 = m, t2 = total;   // (probe)
-          for (;;) {
-              const unsigned long long act2 = __ballot(m2 != 0u);
-              if (!act2 || t2 + 64u > RTW_PAIR_CAP) break;
-              if (m2 != 0u) {
-                  const unsigned z2 = (unsigned)__builtin_ctz(m2);
-                  m2 &= m2 - 1u;
-                  ws.pairs[__builtin_amdgcn_mbcnt_hi((unsigned)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act2, t2))] = code0 - z2;
-              }
-              t2 += (unsigned)__popcll(act2);
-          }
-          __builtin_amdgcn_wave_barrier(); }
-#endif
-        for (;;) {
-            const unsigned long long act = __ballot(m != 0u);
-            if (!act) break;
-            if (total + 64u > ws.cap) {
-                clk.lap(4);
-                resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig);
-                total = 0;
-                clk.lap(5);
-            }
-            if (m != 0u) {
-                const unsigned z = (unsigned)__builtin_ctz(m);
-                m &= m - 1u;
-                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, total));
-                ws.pairs[pos] = code0 - z;
-            }
-            total += (unsigned)__popcll(act);
+        // the lanes with a candidate in this block record their bits, ONE entry each: (bits, recording lane << 16 | block << 5) -- pass 2
+        // walks the bits.  (Until round 5 every BIT became an entry here: a loop of ballot / ctz / mbcnt / write per candidate of the
+        // busiest lane, ~25 - 35 VALU instructions per block with a candidate against 7 now.)
+        const unsigned long long act = __ballot(m != 0u);
+        if (total + 64u > ws.cap) {
+            clk.lap(4);
+            resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig);
+            total = 0;
+            clk.lap(5);
         }
+        RTW_PROBE_EXTRACT_TWICE();
+        if (m != 0u) {
+            const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, total));
+            reinterpret_cast<uint2 *>(ws.pairs)[pos] = uint2{m, lane_const + (unsigned)cur * 32u};
+        }
+        total += (unsigned)__popcll(act);
         clk.lap(4);
     }
     }
     if (use_prio) __builtin_amdgcn_s_setprio(sizeof(T) == 4 ? 1 : 0);
     resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig);
-#ifdef RTW_DUP_RESOLVE_PAIRS   // instruction/time probe: the final resolve twice (idempotent: min / max of the same keys)
-    resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig);
-#endif
+    RTW_PROBE_RESOLVE_TWICE();
     clk.lap(5);
     int idx;
     if constexpr (sizeof(T) == 4) {

@@ -9,7 +9,7 @@ template <typename T, typename SceneT, typename CamT>
 int run_unit(int op_arg, int count, const void *in, void *out, const SceneT *scene, const CamT *cam) {
     const int op = op_arg & 0xff, numerics = (op_arg >> 8) & 3;      // bits 8-9: the numerics mode of the ray-sphere test
     if (op_arg < 0 || (op_arg >> 10) != 0 || op >= rtw::U_NUM_OPS) return fail(-2, "unknown unit op %d", op_arg);
-    if (numerics > rtw::NUM_REFERENCE_FMA2) return fail(-2, "unknown numerics mode %d (unit op %d)", numerics, op_arg);
+    if (numerics == 2) return fail(-2, "unknown numerics mode %d (unit op %d)", numerics, op_arg);
     if (count < 0 || (count > 0 && (!in || !out))) return fail(-1, "null argument");
     if (count == 0) return 0;
     const bool needs_scene = op == rtw::U_HIT_WORLD || op == rtw::U_RAY_COLOR || op == rtw::U_HIT_WORLD_LDS || op == rtw::U_HIT_WORLD_CULL || op == rtw::U_HIT_WORLD_MFMA || op == rtw::U_HIT_WORLD_MFMA_CULL;

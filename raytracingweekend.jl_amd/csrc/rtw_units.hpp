@@ -163,7 +163,7 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
             }
         } break;
         case U_HIT_WORLD_MFMA: {
-            __shared__ unsigned s_pairs[RTW_PAIR_CAP];
+            __shared__ __attribute__((aligned(8))) unsigned s_pairs[RTW_PAIR_CAP];
             __shared__ unsigned long long s_keys[64];
             __shared__ unsigned s_kidx[64];
             V4 *lds_geom = reinterpret_cast<V4 *>(u_smem);
@@ -188,7 +188,7 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
             }
         } break;
         case U_HIT_WORLD_MFMA_CULL: {
-            __shared__ unsigned c_pairs[RTW_PAIR_CAP];
+            __shared__ __attribute__((aligned(8))) unsigned c_pairs[RTW_PAIR_CAP];
             __shared__ unsigned long long c_keys[64];
             __shared__ unsigned c_kidx[64];
             V4 *lds_geom = reinterpret_cast<V4 *>(u_smem);

@@ -28,11 +28,12 @@ def render(scene, cam, image_width=400, n_samples=1, *, depth=16, seed=1, n_chun
     camera's element type, memory-identical to the reference's ``Matrix{RGB{T}}``.
     ``group_cull=True`` selects the opt-in accelerated scan (same image, include/rtw_hip.h);
     ``scan_valu=True`` the all-VALU plain scan (RTW_FLAG_SCAN_VALU: same image, for A/B measurements);
-    ``ray_pool=True`` the ray-pool kernel (RTW_FLAG_RAY_POOL: rays parked in LDS between stages; same image, 14 % slower).
+    ``ray_pool=True`` the ray-pool kernel (RTW_FLAG_RAY_POOL: rays parked in LDS between stages; same image, slower) -- `make POOL=1` builds only,
+    the default library raises RtwError -7.
     ``devices``: ``"all"`` or a list of HIP ordinals -- the 8x8 tiles are dealt to those devices
     inside the library (``rtw_params.n_devices/device_ids``); the image is the same for any list.
     ``numerics``: the deciding arithmetic of ``hit(::Sphere)`` (src/hit.jl:16-18): ``"reference"`` (default: StaticArrays' un-fused
-    dot, one rounding per written operation), ``"reference_fma"`` (the last step contracted), ``"reference_fma2"`` (both squares contracted) or ``"contract"`` (the three FMA
+    dot, one rounding per written operation), ``"reference_fma2"`` (both squares contracted) or ``"contract"`` (the three FMA
     chains of ABI 2); include/rtw_hip.h RTW_FLAG_NUMERICS_*.
     ``rccl_reduce=True`` (with ``devices``): the shards are put together by ONE ncclReduce of zero-padded frames inside the
     library (RTW_FLAG_RCCL_REDUCE) instead of peer copies of compact shards; ``last_stats()["gather_path"]`` says which path ran."""

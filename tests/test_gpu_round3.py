@@ -145,10 +145,10 @@ SOAK_FIXED_SEEDS = [100000, 424242, 31337000, 271828183]      # (even -> the fir
 
 def test_soak_slice():
     """tools/gpu_soak.py: random scenes x 131 072 random rays through the matrix-pipe scan and its block-culling form, then random small
-    renders in all four scan modes and by the ray-pool kernel -- 0 mismatches with the oracle.  (The filter's margin is derived by hand and
-    rests on measured MFMA accumulation behaviour: this is its gate.)  Two parts: a FIXED seed list with a fixed amount of work per seed
-    (a red run reproduces: `python tools/gpu_soak.py <seconds> <seed>`), and a slice with seeds that change from day to day; the seed of
-    every mismatch is in the assertion message."""
+    renders in all four scan modes -- 0 mismatches with the oracle.  (The filter's margin is derived by hand and rests on measured MFMA
+    accumulation behaviour: this is its gate.)  A FIXED seed list with a fixed amount of work per seed: a red run reproduces
+    (`python tools/gpu_soak.py <seconds> <seed>`).  The time-budgeted slice on a seed that changes from day to day is NOT a test any more
+    (round 6: a gate's inputs do not depend on the calendar or the box's speed): `python tools/gpu_soak.py --day` runs it."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gpu_soak
     import rtw_oracle as O
@@ -157,14 +157,8 @@ def test_soak_slice():
         msgs = []
         rounds, rays, bad, _ = gpu_soak.scan_rounds(1e9, seed0, msgs.append, max_rounds=24)
         imgs, bad_imgs, _ = gpu_soak.render_rounds(1e9, seed0, msgs.append, max_rounds=16)
-        assert rounds == 24 and imgs == 16 * 5
+        assert rounds == 24 and imgs == 16 * 4
         assert bad == 0 and bad_imgs == 0, (f"fixed seed {seed0}", msgs[:10])
-    day_seed = 100000 + 1000 * (int(time.time()) // 86400 % 10000)
-    msgs = []
-    rounds, rays, bad, seed = gpu_soak.scan_rounds(25.0, day_seed, msgs.append)
-    imgs, bad_imgs, seed = gpu_soak.render_rounds(12.0, seed, msgs.append)
-    assert rounds >= 3 and rays >= 3 * 2 * 131072 and imgs >= 10, (rounds, rays, imgs)
-    assert bad == 0 and bad_imgs == 0, (f"day seed {day_seed} (seeds {day_seed} .. {seed - 1})", msgs[:10])
 
 
 # ---- generator core and near_zero on the device ---------------------------------------------------------------------------

@@ -29,7 +29,25 @@ def test_library_exports_every_declared_symbol(rtw):
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rtw_abi_version() == _capi.ABI_VERSION == 3
+    assert L.rtw_abi_version() == _capi.ABI_VERSION == 4
+
+
+def test_library_exports_nothing_but_the_c_abi(rtw):
+    """csrc/rtw_exports.map: `nm -D --defined-only` lists exactly the names include/rtw_hip.h declares -- no kernel host stubs, no
+    libstdc++ template instantiations."""
+    import subprocess
+    from rtw_amd import _capi
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert names == sorted(_capi.SYMBOLS), sorted(set(names) ^ set(_capi.SYMBOLS))[:10]
+
+
+def test_make_params_refuses_conflicting_numerics(rtw):
+    from rtw_amd import _capi
+    with pytest.raises(ValueError):
+        _capi.make_params(8, 8, 1, numerics="reference", flags=_capi.FLAG_NUMERICS_CONTRACT)
+    assert _capi.make_params(8, 8, 1, numerics="contract", flags=_capi.FLAG_NUMERICS_CONTRACT).flags == _capi.FLAG_NUMERICS_CONTRACT
+    assert _capi.make_params(8, 8, 1, flags=_capi.FLAG_NUMERICS_CONTRACT).flags == _capi.FLAG_NUMERICS_CONTRACT
 
 
 def test_struct_layouts_match_header(rtw):
@@ -47,9 +65,9 @@ def test_flag_constants_match_header(rtw):
     flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+RTW_FLAG_([A-Z0-9_]+)\s+(\d+)", header)}
     assert flags == {"GROUP_CULL": _capi.FLAG_GROUP_CULL, "COMPACT_TILES": _capi.FLAG_COMPACT_TILES, "SCAN_VALU": _capi.FLAG_SCAN_VALU,
                      "RAY_POOL": _capi.FLAG_RAY_POOL, "RCCL_REDUCE": _capi.FLAG_RCCL_REDUCE,
-                     "NUMERICS_CONTRACT": _capi.FLAG_NUMERICS_CONTRACT, "NUMERICS_REFERENCE_FMA": _capi.FLAG_NUMERICS_REFERENCE_FMA,
+                     "NUMERICS_CONTRACT": _capi.FLAG_NUMERICS_CONTRACT,
                      "NUMERICS_REFERENCE_FMA2": _capi.FLAG_NUMERICS_REFERENCE_FMA2}
-    assert sorted(flags.values()) == [1, 2, 4, 8, 16, 32, 64, 128]
+    assert sorted(flags.values()) == [1, 2, 4, 8, 16, 32, 128]        # (64 was ABI 3's NUMERICS_REFERENCE_FMA)
     jl = open(os.path.join(ROOT, "julia", "RTWeekendHIP.jl")).read()
     assert "(group_cull ? 1 : 0) | (scan_valu ? 4 : 0) | (ray_pool ? 8 : 0) | (rccl_reduce ? 16 : 0)" in jl
 
@@ -180,8 +198,8 @@ def test_julia_shim_struct_layouts_match_the_c_abi():
         cf = [(n, getattr(ct, n).offset, getattr(ct, n).size) for n, _ in ct._fields_]
         assert [(o, s) for _, o, s in lay] == [(o, s) for _, o, s in cf], (jl, lay, cf)
         assert [n for n, _, _ in lay] == [n for n, _, _ in cf], jl
-    assert "v == 3 ||" in src and _capi.ABI_VERSION == 3
-    assert "numerics === :contract ? 32 : numerics === :reference_fma ? 64 : numerics === :reference_fma2 ? 128 : 0" in src            # the flag bits of include/rtw_hip.h
+    assert "v == 4 ||" in src and _capi.ABI_VERSION == 4
+    assert "numerics === :contract ? 32 : numerics === :reference_fma2 ? 128 : 0" in src            # the flag bits of include/rtw_hip.h
 
 
 def test_check_julia_kat_detects_a_wrong_assumption(tmp_path):

@@ -247,6 +247,7 @@ def check(path):
         if len(f32) == 1:
             mode = f32[0]
             print(f"  -> this Julia evaluates src/hit.jl:16-18 as the oracle's `{mode}` mode" + (" (the library's default)" if mode == "reference" else
+                  ": ORACLE-ONLY since ABI 4 (the library dropped it in round 6 because no compiler was known to emit it): restore RTW_FLAG_NUMERICS_REFERENCE_FMA from git history" if mode == "reference_fma" else
                   f": make it the default (include/rtw_hip.h RTW_FLAG_NUMERICS_*; `numerics` of render()), or pass numerics={mode!r}"
                  ))
         elif not f32:

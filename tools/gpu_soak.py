@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test of the matrix-pipe filter: random scans (unit ops 13 and 14 vs the oracle) with fresh seeds for a
 given number of seconds, then random small renders in every scan mode vs the oracle; the numerics mode of the ray-sphere test
-(reference / contract / reference_fma) changes with the seed, on both sides.
+(reference / contract / reference_fma2) changes with the seed, on both sides.
 usage: python tools/gpu_soak.py [seconds=300] [first_seed=1000]   (needs the GPU; prints one summary line per part)
 A 60-second slice of the same two loops gates the GPU suite: tests/test_gpu_round3.py::test_soak_slice."""
 import os, sys, time
@@ -11,14 +11,14 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 import numpy as np
 
-NUMERICS = ("reference", "contract", "reference_fma", "reference_fma2")      # the numerics mode of a round follows its seed: all four are soaked
+NUMERICS = ("reference", "contract", "reference_fma2")      # the numerics mode of a round follows its seed: all three are soaked
 
 
 def _set_numerics(seed):
     """both sides -- the oracle and the product's Python mirror -- to the mode of this seed; returns (mode, restore())"""
     import rtw_oracle as O
     from rtw_amd import _capi
-    mode = NUMERICS[(seed // 2) % 4]
+    mode = NUMERICS[(seed // 2) % 3]
     prev = (O.set_numerics(mode), _capi.set_default_numerics(mode))
     return mode, (lambda: (O.set_numerics(prev[0]), _capi.set_default_numerics(prev[1])))
 
@@ -56,7 +56,7 @@ def scan_rounds(seconds, seed, log=print, max_rounds=None):
 
 
 def render_rounds(seconds, seed, log=print, max_rounds=None):
-    """Random small scenes / cameras rendered in all four scan modes and by the ray-pool kernel vs the oracle.  -> (images, mismatches, next seed)
+    """Random small scenes / cameras rendered in all four scan modes (RTW_TEST_POOL=1, a `make POOL=1` library: also by the ray-pool kernel) vs the oracle.  -> (images, mismatches, next seed)
     `max_rounds`: stop after that many scenes (a reproducible amount of work for a fixed seed list)"""
     import rtw_oracle as O
     import rtw_amd as R
@@ -81,7 +81,7 @@ def render_rounds(seconds, seed, log=print, max_rounds=None):
         camd = {k: np.asarray(getattr(cam, k)) for k in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w", "lens_radius")}
         g = dict(g0, flat=flat, cam=camd, image=np.zeros((1, 1, 3), T))
         ref, ost = O.render(flat, cam, 64, 36, 6, T=T, max_depth=12, seed=seed, n_chunks=3)
-        for flags in (0, 4, 1, 5, 8):           # matrix-pipe scan, all-VALU scan, cull, all-VALU cull, ray-pool kernel (Float32; ignored for Float64)
+        for flags in (0, 4, 1, 5) + ((8,) if os.environ.get("RTW_TEST_POOL") == "1" else ()):     # matrix-pipe scan, all-VALU scan, cull, all-VALU cull (+ the ray-pool kernel of a POOL=1 build)
             img, st = gpu_render(g, width=64, height=36, spp=6, n_chunks=3, max_depth=12, seed=seed, flags=flags)
             imgs += 1
             if not (np.array_equal(img, ref, equal_nan=True) and st.segments == ost["segments"]):
@@ -95,13 +95,17 @@ def render_rounds(seconds, seed, log=print, max_rounds=None):
 
 if __name__ == "__main__":
     import rtw_oracle as O
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    if len(sys.argv) > 1 and sys.argv[1] == "--day":      # the rolling slice that was half of tests/test_gpu_round3.py::test_soak_slice until round 5
+        budget, seed = (float(sys.argv[2]) if len(sys.argv) > 2 else 40.0), 100000 + 1000 * (int(time.time()) // 86400 % 10000)
+        print(f"day seed {seed}", flush=True)
+    else:
+        budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+        seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     O.build(); O.lib()
     t0 = time.time()
     say = lambda s: print(s, flush=True)
     rounds, rays_total, bad_total, seed = scan_rounds(budget * 0.7, seed, say)
     say(f"scan soak: {rounds} rounds, {rays_total} rays, {bad_total} mismatches, {time.time() - t0:.0f} s")
     imgs, bad_imgs, seed = render_rounds(budget - (time.time() - t0), seed, say)
-    say(f"render soak: {imgs} images (all four scan modes + the ray-pool kernel), {bad_imgs} mismatches; total {time.time() - t0:.0f} s")
+    say(f"render soak: {imgs} images (all four scan modes), {bad_imgs} mismatches; total {time.time() - t0:.0f} s")
     sys.exit(1 if (bad_total or bad_imgs) else 0)

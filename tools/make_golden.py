@@ -19,7 +19,7 @@ import rtw_amd as R          # noqa: E402  (host mirror: scene / camera producer
 import rtw_oracle as O       # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
-MODES = ("reference", "contract", "reference_fma", "reference_fma2")
+MODES = ("reference", "contract", "reference_fma2")       # the numerics modes of the library (include/rtw_hip.h RTW_FLAG_NUMERICS_*)
 
 
 def cam_dict(cam):
