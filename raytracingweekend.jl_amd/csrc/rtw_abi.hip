@@ -69,7 +69,8 @@ int acquire_rec(DeviceCtx *ctx, RenderRec **out) {
     r->device = ctx->device;
     HIP_TRY(hipMalloc(&r->ctr, sizeof(rtw::DevCounters)));
     HIP_TRY(hipHostMalloc((void **)&r->h_ctr, sizeof(rtw::DevCounters), hipHostMallocDefault));
-    HIP_TRY(hipMemset(r->ctr, 0, sizeof(rtw::DevCounters)));           // (a render clears the head only, unless it profiles the drain)
+    r->fresh = true;        // (its first render clears ALL of the counters, on its own stream: a hipMemset here would run on the null stream, which
+                            //  the non-blocking streams of the renders do not wait for -- it could land in the middle of the first kernel)
     HIP_TRY(hipEventCreate(&r->ev0));
     HIP_TRY(hipEventCreate(&r->ev1));
     HIP_TRY(hipEventCreateWithFlags(&r->ev2, hipEventDisableTiming));

@@ -105,6 +105,7 @@ struct RenderRec {
     bool used = false;                   // ev1 has been recorded at least once
     bool done = true;                    // the kernel recorded by ev1 is known to have finished (no hipEventQuery needed)
     bool owned = false;                  // referenced by some thread's "last render"
+    bool fresh = true;                   // the device counters have never been cleared as a whole
     int n_spheres = 0, n_chunks = 0, grid = 0, block = 256;
     ~RenderRec() {
         if (ctr) HIP_IGNORE(hipFree(ctr));

@@ -32,6 +32,7 @@ namespace rtw {
 #define RTW_SLOT_OPENING 0xfffffffeu       // (the ray-pool kernel's marker)
 #define RTW_SLOT_OPENING_BIT 0x80000000u   // lane loop: ready_seq = this bit + the job's sequence number while its opener claims the job
 #define RTW_JOB_EOF 0xffffffffu
+#define RTW_JOB_RETRY 0xfffffffeu          // open_job: no job YET (another wave is refilling the workgroup's job cache) -- the lane loop asks again
 
 struct KParams {
     int width, height, spp, max_depth;
@@ -104,6 +105,7 @@ template <bool ON> struct PhaseClock {
     __device__ __forceinline__ void lap(int k) {
         if (ON) { unsigned long long t = __builtin_readcyclecounter(); acc[k] += t - t0; t0 = t; }
     }
+    static constexpr bool on() { return ON; }
     __device__ __forceinline__ void count(int k, unsigned n) { if (ON) acc[k] += n; }      // event counters in the cells 6 .. 15
 };
 
@@ -235,7 +237,11 @@ __device__ __forceinline__ unsigned queue_positions(const KParams &P, unsigned x
 // same 2.3 ms of drain) with 30.1 instead of 43.0 MB of WRITE_SIZE; RTW_CLAIM_TAIL 8: 11 - 13 ms of drain; 24: +0.6 MB.
 // (Rejected: claims of 8 positions FAR APART in the frame -- no drain, but 1 % slower for the lost coherence, see above; a
 // static share of the queue per workgroup, no atomics at all -- the workgroups' shares differ by +-35 % in cost, 438 ms.)
-// Another die's queue is only ever visited at its end: single claims there.  Returns false when every queue is exhausted.
+// Another die's queue is only ever visited at its end: single claims there.  Returns 1 with a job, 0 when every queue is exhausted FOR GOOD,
+// 2 (try again) when this caller found the queues exhausted WITHOUT holding the refill lock: the lock's holder may be about to publish
+// positions it has claimed (what it publishes are jobs; "exhausted" must not be concluded over its head -- since round 6 one such conclusion
+// ends the whole workgroup, see sh->eof in the lane loop).  Under the lock "exhausted" is final: the cache is empty, only lock holders fill
+// it, and the queue counters never come back.
 #ifndef RTW_JOB_CLAIM
 #define RTW_JOB_CLAIM 8u
 #endif
@@ -248,6 +254,9 @@ __device__ __forceinline__ unsigned queue_positions(const KParams &P, unsigned x
 // once: 5 120 returning atomics on 8 addresses are executed one after the other by the memory side -- measured on a 96 x 54 frame:
 // 166 us of kernel time with them, 64 us with jobs so large that a quarter as many were claimed; on 320 x 180 x 64 spp the start-up is
 // 10 % of the frame.  (Which workgroup renders which job does not matter to the image.)
+#ifndef RTW_OPEN_RETRY
+#define RTW_OPEN_RETRY 1      // (0: debugging aid -- an opener whose claim must be repeated spins in open_job instead of giving its slot back)
+#endif
 #ifndef RTW_STATIC_CLAIMS
 #define RTW_STATIC_CLAIMS 4u
 #endif
@@ -259,19 +268,19 @@ __device__ __forceinline__ unsigned static_claims(unsigned xq, unsigned q_pos) {
     return k < RTW_STATIC_CLAIMS ? k : RTW_STATIC_CLAIMS;
 }
 __device__ __forceinline__ unsigned static_base(unsigned xq, unsigned q_pos) { return static_claims(xq, q_pos) * ((gridDim.x + 7u - xq) >> 3); }
-__device__ __forceinline__ bool claim_job(const KParams &P, DevCounters *ctr, JobCache *C, unsigned xcd, unsigned sub_shift, unsigned &xq_out, unsigned &gq_out) {
+__device__ __forceinline__ int claim_job(const KParams &P, DevCounters *ctr, JobCache *C, unsigned xcd, unsigned sub_shift, unsigned &xq_out, unsigned &gq_out) {
     constexpr unsigned long long M28 = (1ull << 28) - 1ull;
     if (__hip_atomic_load(&C->static_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < RTW_STATIC_CLAIMS) {
         const unsigned k = __hip_atomic_fetch_add(&C->static_used, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned xq = blockIdx.x & 7u, ks = static_claims(xq, queue_positions(P, xq, sub_shift));
-        if (k < ks) { xq_out = xq; gq_out = (blockIdx.x >> 3) * ks + k; return true; }
+        if (k < ks) { xq_out = xq; gq_out = (blockIdx.x >> 3) * ks + k; return 1; }
     }
     for (;;) {
         unsigned long long w = __hip_atomic_load(&C->jc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         while ((w & M28) < ((w >> 28) & M28)) {                    // cached positions: take one
             if (__hip_atomic_compare_exchange_strong(&C->jc, &w, w + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                 xq_out = (unsigned)(w >> 56); gq_out = (unsigned)(w & M28);
-                return true;
+                return 1;
             }
         }
         unsigned expect = 0u;
@@ -303,12 +312,15 @@ __device__ __forceinline__ bool claim_job(const KParams &P, DevCounters *ctr, Jo
         }
         __hip_atomic_store(&C->queue_off, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (locked) __hip_atomic_store(&C->jc_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return got;
+        return got ? 1 : (locked ? 0 : 2);
     }
 }
 
 // Open a job slot (whole wave): take job ids from the queues until one has a pixel inside the
 // image (or every queue is exhausted), zero its accumulators and fill in the block's header.
+// S->job: the job's queue position, RTW_JOB_EOF (every queue is exhausted for good) or -- WITH_RETRY only -- RTW_JOB_RETRY (claim_job's "try again";
+// without WITH_RETRY the claim is repeated here until it is decided).
+template <bool WITH_RETRY = false>
 __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned lane, DevCounters *ctr, JobCache *jcache) {
     unsigned g = RTW_JOB_EOF, valid = 0, k = 0;
     int i_base = 0, j_base = 0;
@@ -316,8 +328,10 @@ __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned la
     const unsigned xcd = xcd_id();
     for (;;) {
         unsigned xq = 0, gq = 0, ok = 0;
-        if (lane == 0) ok = claim_job(P, ctr, jcache, xcd, sub_shift, xq, gq) ? 1u : 0u;
-        if (!uniform(ok)) break;
+        if (lane == 0) ok = (unsigned)claim_job(P, ctr, jcache, xcd, sub_shift, xq, gq);
+        ok = uniform(ok);
+        if (ok == 2u) { if (WITH_RETRY) { g = RTW_JOB_RETRY; break; } __builtin_amdgcn_s_sleep(1); continue; }
+        if (!ok) break;
         xq = uniform(xq); gq = uniform(gq);
         const unsigned qt = gq >> sub_shift, q = gq & ((1u << sub_shift) - 1u);      // tile within the queue, block within the tile
         unsigned tj, ti;
@@ -336,7 +350,7 @@ __device__ RTW_RARE_ATTR void open_job(const KParams &P, JobSlot *S, unsigned la
         valid = (unsigned)__ballot(lane < (1u << P.job_shift) && i0 < P.height && j0 < P.width);
         if (valid) { g = gq; break; }                            // (blocks entirely outside the image are skipped)
     }
-    if (g != RTW_JOB_EOF) {
+    if (g < RTW_JOB_RETRY) {
         if (lane < (4u << P.job_shift)) {
             unsigned zero = 0u;
             __asm__ volatile("" : "+v"(zero));       // (made here: a hoisted zero quad costs 4 loop-long registers)
@@ -516,9 +530,10 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             // straggler (a 50-bounce path inside the glass sphere) holds ITS slot only; with the slots used as a ring it blocked every
             // later job of the workgroup (measured at 1080p: 11 % of the lane-iterations lost at 200 spp, 69 % at 64 spp).
             //   ready_seq:  RTW_SLOT_FREE | RTW_SLOT_OPENING_BIT + seq (its opener is claiming a job) | seq (open)
-            //   sh->eof:    set, before the slot is given back, by an opener whose claim found every queue exhausted.  Claims fail
-            //               for good once one has failed, and an opener advertises its slot BEFORE it claims: a wave that reads eof
-            //               first and then finds its job neither open nor opening knows that the job does not exist.
+            //   sh->eof:    set, before the slot is given back, by an opener whose claim found every queue exhausted FOR GOOD (claim_job's 0,
+            //               decided under the refill lock: from then on every claim of this workgroup fails).  An opener advertises its
+            //               slot BEFORE it claims: a wave that reads eof first and then finds its job neither open nor opening knows
+            //               that the job does not exist.
 #pragma unroll 1
             for (int round = 0; round < 2; ++round) {
                 const bool taker = need && alive && !have_item;
@@ -550,13 +565,16 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
                         }
                         if (uniform(won)) {
-                            open_job(P, S, lane, ctr, &sh->jobs);
-                            if (uniform(S->job) == RTW_JOB_EOF) {
-                                if (lane == 0) __hip_atomic_store(&sh->eof, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            open_job<RTW_OPEN_RETRY != 0>(P, S, lane, ctr, &sh->jobs);
+                            const unsigned opened = uniform(S->job);
+                            if (opened >= RTW_JOB_RETRY) {
+                                if (opened == RTW_JOB_EOF && lane == 0) __hip_atomic_store(&sh->eof, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 __hip_atomic_store(&S->ready_seq, RTW_SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (taker) alive = false;                     // the global queues are exhausted: these lanes are done
-                                have_ticket = false;
-                                break;
+                                if (opened == RTW_JOB_EOF) {
+                                    if (taker) alive = false;                 // the global queues are exhausted: these lanes are done
+                                    have_ticket = false;
+                                }
+                                break;                                        // (RTW_JOB_RETRY: the ticket is kept, the slot given back: ask again in the next iteration)
                             }
                             __hip_atomic_store(&S->ready_seq, tk_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                             m_mine = 1ull << sl;

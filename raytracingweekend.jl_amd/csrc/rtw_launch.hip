@@ -185,7 +185,8 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     static const bool drain_profile = aid_env("RTW_DRAIN_PROFILE") != nullptr;
     K.drain_profile = drain_profile ? 1 : 0;
     rec->ctr_bytes = (drain_profile || phase_profile || pool) ? sizeof(rtw::DevCounters) : offsetof(rtw::DevCounters, t_first);    // (the ray-pool kernel keeps its stage profile / watchdog state in the histogram cells)
-    HIP_TRY(hipMemsetAsync(rec->ctr, 0, rec->ctr_bytes, stream));
+    HIP_TRY(hipMemsetAsync(rec->ctr, 0, rec->fresh ? sizeof(rtw::DevCounters) : rec->ctr_bytes, stream));
+    rec->fresh = false;
     if (drain_profile) HIP_TRY(hipMemsetAsync(&rec->ctr->t_first, 0xff, sizeof(unsigned long long), stream));
     // pixels of other shards read 0 in the full-frame layout (the sum over the shards is the image)
     if (K.out_layout == 0 && p->shard_count > 1)
@@ -215,6 +216,12 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
     float k_ms = 0;
     HIP_TRY(hipEventElapsedTime(&k_ms, r->ev0, r->ev1));
     const rtw::DevCounters &c = *r->h_ctr;         // (the copy that followed the kernel on its stream; the drain part only with RTW_DRAIN_PROFILE)
+    if (aid_env("RTW_DEBUG")) {
+        rtw::DevCounters chk;
+        HIP_TRY(hipMemcpy(&chk, r->ctr, offsetof(rtw::DevCounters, t_first), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[rtw debug] resolve rec %p dev %d grid %d: pinned copy samples %llu segments %llu | device now samples %llu segments %llu%s\n", (void *)r, r->device, r->grid,
+                (unsigned long long)c.samples, (unsigned long long)c.segments, (unsigned long long)chk.samples, (unsigned long long)chk.segments, c.samples != chk.samples ? "  <-- STALE" : "");
+    }
     if (aid_env("RTW_PHASE_PROFILE") && r->block != 256) {
         const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(c.end_hist + 256);
         static const char *names[6] = {"SCAN", "LM", "END", "DIEL", "REJ", "WAIT"};
@@ -235,6 +242,9 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
                             "lane-iterations lost at batch boundaries %.2f %% (pool short) + %.2f %% (no usable batch)\n", (unsigned long long)c.phase[8],
                     100.0 * (double)c.phase[9] / (64.0 * (double)c.phase[8]), (unsigned long long)c.phase[9], 100.0 * (double)c.phase[10] / (double)c.phase[8],
                     100.0 * (double)c.phase[11] / (64.0 * (double)c.phase[8]), 100.0 * (double)c.phase[12] / (64.0 * (double)c.phase[8]));
+        if (c.phase[8] && c.phase[13])
+            fprintf(stderr, "[rtw phase profile] pass 2: %.1f list entries, %.2f exact-test rounds and %.1f exact tests per wave-iteration (lanes busy in a round: %.1f %%)\n",
+                    (double)c.phase[13] / (double)c.phase[8], (double)c.phase[14] / (double)c.phase[8], (double)c.phase[15] / (double)c.phase[8], 100.0 * (double)c.phase[15] / (64.0 * (double)c.phase[14]));
         if (c.phase[7])
             fprintf(stderr, "[rtw phase profile] matrix-pipe scan: %.1f%% of the (wave, block of 32 spheres) evaluations found no candidate in any lane (%llu of %llu)\n",
                     100.0 * (double)c.phase[6] / (double)c.phase[7], (unsigned long long)c.phase[6], (unsigned long long)c.phase[7]);

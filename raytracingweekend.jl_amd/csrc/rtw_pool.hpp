@@ -158,7 +158,7 @@ __global__ __launch_bounds__(W * 64, (W + 3) / 4) void trace_pool_kernel(KParams
     ws.pairs = reinterpret_cast<unsigned *>(smem) + wv * RTW_POOL_PAIR_CAP;
     ws.keys = reinterpret_cast<unsigned long long *>(smem + pairs_bytes) + wv * 64;
     ws.kidx = reinterpret_cast<unsigned *>(smem + pairs_bytes + (size_t)W * 64 * 8) + wv * 64;
-    ws.cap = RTW_POOL_PAIR_CAP / 2;          // (entries of two words)
+    ws.cap = 80; ws.cap2 = RTW_POOL_PAIR_CAP - 160;          // (entries of two words + single candidates)
 
     // ---- set-up: every slot starts in END, "nothing to add, needs an item" ----
     for (unsigned i = threadIdx.x; i < PQ_COUNT * RTW_POOL_RING; i += W * 64) {

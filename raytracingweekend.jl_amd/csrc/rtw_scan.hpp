@@ -64,7 +64,7 @@ template <typename T> struct ScanGroup;
 template <> struct ScanGroup<float> { static constexpr int N = 4; };    // 4 x 16 B = 1 x s_load_dwordx16
 template <> struct ScanGroup<double> { static constexpr int N = 4; };   // 4 x 8 floats = 2 x s_load_dwordx16
 
-struct NoClock { __device__ __forceinline__ void lap(int) {} __device__ __forceinline__ void count(int, unsigned) {} };
+struct NoClock { static constexpr bool on() { return false; } __device__ __forceinline__ void lap(int) {} __device__ __forceinline__ void count(int, unsigned) {} };
 
 // src/hit.jl:38-50 -- closest hit by linear scan over ALL spheres; `closest` shrinks; a later
 // sphere wins an exact tie.  Same results as the plain loop, organised for the wave:

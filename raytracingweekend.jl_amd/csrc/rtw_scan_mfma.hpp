@@ -71,7 +71,7 @@ namespace rtw {
 // else the far root if that is -- and the LAST sphere among exact ties; a sphere whose near root exceeds the running
 // closest cannot win with its far root either.  That is the minimum of the 64-bit keys (root bits, ~sphere): one LDS
 // atomic min per accepted candidate (Float64: min on the root bits, then max on the index among the candidates equal to it).
-#define RTW_PAIR_CAP 512     // 32-bit words of a wave's candidate list: 256 entries of (bits, lane << 16 | block << 5); a full list is resolved early
+#define RTW_PAIR_CAP 512     // 32-bit words of a wave's candidate list area: 160 entries of (bits, lane << 16 | block << 5) + 192 single candidates; a full list is resolved early
 typedef _Float16 rtw_h8 __attribute__((ext_vector_type(8)));
 typedef float rtw_f16v __attribute__((ext_vector_type(16)));
 
@@ -109,7 +109,8 @@ struct WaveScratch {
     unsigned *pairs;              // the wave's candidate list, 8-byte aligned: entries of two words (see resolve_pairs)
     unsigned long long *keys;     // 64 entries: Float32 (root bits << 32 | ~sphere); Float64 root bits
     unsigned *kidx;               // Float64 only: 64 entries, sphere + 1
-    unsigned cap = RTW_PAIR_CAP / 2;  // ENTRIES in `pairs` (wave-uniform; the ray-pool kernel gives a wave 128)
+    unsigned cap = 5 * RTW_PAIR_CAP / 16; // ENTRIES (two words each) at the start of `pairs`: 160 -- a scan of the headline scene records ~50 ...
+    unsigned cap2 = 3 * RTW_PAIR_CAP / 8; // ... and single candidates (one word each) behind them: 192 -- ~70 per scan there; the exact tests run when 128 are waiting or the scan ends.  (The ray-pool kernel gives a wave half the area.)
 };
 
 // x = p1 + p2 with p1 = RN16(x), p2 = RN16(x - p1); returns p1 | p2 << 16
@@ -133,33 +134,33 @@ __device__ __forceinline__ double lane_get(double v, unsigned src_lane) {
 
 // (Rejected and removed in round 6, in git history: flagging GROUPS of 2 / 4 spheres per list entry -- 380.5 / 388.0 against 370.9 ms, pass 2 pays
 // one exact test per member --, and collecting the signs by v_cmp into SGPR lane masks -- +4.7 %.)
+#ifndef RTW_PRECHECK_GROUPS
+#define RTW_PRECHECK_GROUPS 1   // groups per half block whose sign collection is skipped separately (hit_world_mfma): 1, 2 or 4
+#endif
 #ifndef RTW_SCAN_SKIP
 #define RTW_SCAN_SKIP 1      // wave-level early-out per half block (hit_world_mfma): 372.2 vs 376.3 ms.  (Left to the compiler it is
                              // if-converted -- both sides executed -- and gains nothing: the sign collection's side is fenced by an asm.)
 #endif
 
-// Walk n entries of the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).
+// Pass 2 over the wave's list (all 64 lanes; src = the scene's geom in LDS or global memory).  The block loop records ONE entry per (lane, block)
+// with a candidate: (x: the lane's candidate bits of the block, bit 31 - b for b = half << 4 | result register; y: recording lane (H, j) << 16 |
+// block << 5).  Here the entries are first EXPLODED into single candidates (y | b) in the second half of the list area -- the ballot / ctz /
+// mbcnt / write loop that ran once per BLOCK until round 5 (25 - 35 VALU instructions per block with a candidate; now 7 there and this loop
+// once per 64 entries) -- and then the exact test runs on full rounds of 64 candidates whatever their owner.  (Walking the bits of an entry in
+// the lane that holds it was measured too: 3.3 rounds of exact tests at 33 % lane utilisation per scan instead of 1.5 -- candidates of one ray in
+// one block come in runs, the list order of the reference's scene is a row of the lattice.)
 struct NoOrig {};
 template <typename T, bool WITH_R, typename SRC, typename ORIG = NoOrig>
-__device__ __forceinline__ void resolve_pairs_impl(int num, SRC src, [[maybe_unused]] const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
+__device__ __forceinline__ void test_singles(int num, SRC src, [[maybe_unused]] const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, const unsigned *singles, unsigned n, unsigned lane, ORIG orig, unsigned *prof) {
     constexpr bool CULLED = !__is_same(ORIG, NoOrig);      // device order != the caller's order: ties go by orig[], the key carries both
     using V4 = typename Vec4<T>::type;
-    __builtin_amdgcn_wave_barrier();
-    const uint2 *list = reinterpret_cast<const uint2 *>(ws.pairs);
     for (unsigned p0 = 0; p0 < n; p0 += 64u) {
         const unsigned p = p0 + lane;
-        const uint2 e = list[p < n ? p : 0u];
-        // entry = (x: the recording lane's candidate bits of one block, bit 31 - b for b = half << 4 | result register,
-        //          y: recording lane (H, j) << 16 | block << 5): ray j + 32 (b >> 4), sphere 32 block + 16 H + (b & 15).
-        // A lane walks the bits of its entry; two bits are common (lanes j and j + 32 of a wave start as two chunks of one pixel: both
-        // halves see the same sphere), so the walk is the second "round" that a list of single candidates needed anyway.
-        unsigned m = p < n ? e.x : 0u;
-        const unsigned code = e.y;
-        while (__any(m != 0u)) {
-        const bool valid = m != 0u;
-        const unsigned b = 31u - (unsigned)__builtin_ctz(m | 0x80000000u);      // (a lane without a bit left: b = 0 of its entry -- a valid address, result unused)
-        m &= m - 1u;
-        const unsigned owner = ((code >> 16) & 31u) + ((b & 16u) << 1), sph = (code & 0xffe0u) + ((code >> 17) & 16u) + (b & 15u);
+        const bool valid = p < n;
+        const unsigned e = singles[valid ? p : 0u];
+        if (prof) { prof[0] += 1u; prof[1] += (unsigned)__popcll(__ballot(valid)); }        // (phase-profile build: rounds of exact tests, lanes that had one)
+        // candidate = recording lane (H, j) << 16 | block << 5 | b,  b = half << 4 | result register: ray j + 32 (b >> 4), sphere 32 block + 16 H + (b & 15)
+        const unsigned owner = ((e >> 16) & 31u) + ((e & 16u) << 1), sph = (e & 0xffefu) + ((e >> 17) & 16u);
         const V3<T> po = {lane_get(o.x, owner), lane_get(o.y, owner), lane_get(o.z, owner)};
         const V3<T> pd = {lane_get(d.x, owner), lane_get(d.y, owner), lane_get(d.z, owner)};
         const V4 s = src[sph];
@@ -186,16 +187,46 @@ __device__ __forceinline__ void resolve_pairs_impl(int num, SRC src, [[maybe_unu
             if (hit && tb == cur) __hip_atomic_fetch_max(&ws.kidx[owner], tie + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_wave_barrier();
         }
+    }
+}
+template <typename T, bool WITH_R, typename SRC, typename ORIG = NoOrig>
+__device__ __forceinline__ void resolve_pairs_impl(int num, SRC src, [[maybe_unused]] const typename Vec4<T>::type *rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG(), unsigned *prof = nullptr) {
+    __builtin_amdgcn_wave_barrier();
+    const uint2 *list = reinterpret_cast<const uint2 *>(ws.pairs);
+    unsigned *singles = ws.pairs + 2u * ws.cap;            // ws.cap2 words behind the ws.cap entries
+    unsigned total = 0;                                    // (wave-uniform) single candidates waiting for their exact test
+    for (unsigned p0 = 0; p0 < n; p0 += 64u) {
+        const unsigned p = p0 + lane;
+        const uint2 e = list[p < n ? p : 0u];
+        unsigned m = p < n ? e.x : 0u;
+        const unsigned code31 = e.y + 31u;
+        for (;;) {
+            const unsigned long long act = __ballot(m != 0u);
+            if (!act) break;
+            if (total + 64u > ws.cap2) {
+                __builtin_amdgcn_wave_barrier();
+                test_singles<T, WITH_R>(num, src, rad, o, d, tmin, ws, singles, total, lane, orig, prof);
+                __builtin_amdgcn_wave_barrier();
+                total = 0;
+            }
+            if (m != 0u) {
+                const unsigned z = (unsigned)__builtin_ctz(m);
+                m &= m - 1u;
+                singles[__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, total))] = code31 - z;     // b = 31 - z
+            }
+            total += (unsigned)__popcll(act);
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    test_singles<T, WITH_R>(num, src, rad, o, d, tmin, ws, singles, total, lane, orig, prof);
     __builtin_amdgcn_wave_barrier();
 }
 
 // (NUM_REFERENCE_FMA2 reads the radius from mat0: its own copy of the loop, so that the other modes keep their registers)
 template <typename T, typename SRC, typename RAD, typename ORIG = NoOrig>
-__device__ __forceinline__ void resolve_pairs(int num, SRC src, RAD rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG()) {
-    if (num == NUM_REFERENCE_FMA2) resolve_pairs_impl<T, true>(num, src, rad(), o, d, tmin, ws, n, lane, orig);
-    else resolve_pairs_impl<T, false>(num, src, nullptr, o, d, tmin, ws, n, lane, orig);
+__device__ __forceinline__ void resolve_pairs(int num, SRC src, RAD rad, V3<T> o, V3<T> d, T tmin, const WaveScratch &ws, unsigned n, unsigned lane, ORIG orig = ORIG(), unsigned *prof = nullptr) {
+    if (num == NUM_REFERENCE_FMA2) resolve_pairs_impl<T, true>(num, src, rad(), o, d, tmin, ws, n, lane, orig, prof);
+    else resolve_pairs_impl<T, false>(num, src, nullptr, o, d, tmin, ws, n, lane, orig, prof);
 }
 
 // Closest hit for the rays of a whole wave (every lane calls it, convergently; has_ray = this lane has a ray).
@@ -416,19 +447,33 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         unsigned mask = 0;
         bool any_cand = false;                               // (wave-uniform)
         const rtw_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        auto eval = [&](const rtw_f16v &Wv) {
+        // Sign collection of one half block's 16 filter values: one slow-class v_alignbit_b32 per value.  Most (wave, half block)
+        // evaluations find no candidate in ANY lane (rays of a wave are neighbours), so the sign bits of a GROUP of values are ANDed first
+        // (FMA-class v_bitop3_b32 / v_and_b32, one per two values) and the alignbits of the group run only when some lane has a
+        // non-negative value in it.  RTW_PRECHECK_GROUPS groups per half block: 1 = all 16 values at once (rounds 3 - 5), 2 = two groups of 8.
+        // (Left to the compiler the skip is if-converted -- both sides executed -- and gains nothing: the collecting side is fenced by an asm.)
+        auto collect = [&](rtw_f16v &Wv) {
+            constexpr int NG = RTW_PRECHECK_GROUPS, GS = 16 / NG;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int r0 = g * GS;
+                unsigned t = __builtin_amdgcn_bitop3_b32(__float_as_uint(Wv[r0]), __float_as_uint(Wv[r0 + 1]), __float_as_uint(Wv[r0 + 2]), 0x80);
+#pragma unroll
+                for (int r = r0 + 3; r < r0 + GS - 1; r += 2) t = __builtin_amdgcn_bitop3_b32(t, __float_as_uint(Wv[r]), __float_as_uint(Wv[r + 1]), 0x80);
+                t &= __float_as_uint(Wv[r0 + GS - 1]);
+                if (RTW_SCAN_SKIP && !__any((int)t >= 0)) {
+                    mask = (mask << GS) | ((1u << GS) - 1u);                       // all negative: no lane has a candidate in this group
+                } else {
+                    if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv));
+#pragma unroll
+                    for (int r = r0; r < r0 + GS; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]), 31);
+                    any_cand = true;
+                }
+            }
+        };
+        [[maybe_unused]] auto eval = [&](const rtw_f16v &Wv) {            // (rtw_probes.hpp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]), 31);
-        };
-        // Half of the (wave, block) evaluations find no candidate in ANY lane (rays of a wave are neighbours): the sign bits of
-        // a half block's 16 filter values are ANDed first (8 FMA-class v_bitop3_b32 / v_and_b32) and the 16 slow-class
-        // v_alignbit_b32 run only when some lane has a non-negative value.  true = no lane has a candidate in Wv.
-        auto none = [&](const rtw_f16v &Wv) -> bool {
-            unsigned t = __builtin_amdgcn_bitop3_b32(__float_as_uint(Wv[0]), __float_as_uint(Wv[1]), __float_as_uint(Wv[2]), 0x80);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) t = __builtin_amdgcn_bitop3_b32(t, __float_as_uint(Wv[r]), __float_as_uint(Wv[r + 1]), 0x80);
-            t &= __float_as_uint(Wv[15]);
-            return !__any((int)t >= 0);
         };
         // the filter values of one half block (32 spheres x 32 rays): two chained MFMAs (rtw_probes.hpp: time probes that repeat / replace them)
         auto filter_pair = [&](const uint4 &a1, const uint4 &a2, const rtw_h8 &b1, const rtw_h8 &b2) -> rtw_f16v {
@@ -443,8 +488,8 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             rtw_f16v Wv = zero;
             if (!CULLED || do_half0) Wv = filter_pair(A1, A2, B1[0], B2[0]);
             RTW_PROBE_EVAL_TWICE(Wv);
-            if ((CULLED && !do_half0) || (RTW_SCAN_SKIP && none(Wv))) mask = (1u << HB) - 1u;          // all negative
-            else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }      // (the asm keeps it a real branch: no if-conversion)
+            if (CULLED && !do_half0) mask = (1u << HB) - 1u;          // (no ray of this half can touch the block)
+            else collect(Wv);
         }
         {
             // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
@@ -455,8 +500,8 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             A1 = pa[blk * 128]; A2 = pa[blk * 128 + 64];
             __builtin_amdgcn_sched_barrier(0);
             RTW_PROBE_EVAL_TWICE(Wv);
-            if ((CULLED && !do_half1) || (RTW_SCAN_SKIP && none(Wv))) mask = (mask << HB) | ((1u << HB) - 1u);
-            else { if (RTW_SCAN_SKIP) __asm__ volatile("" : "+v"(Wv)); eval(Wv); any_cand = true; }
+            if (CULLED && !do_half1) mask = (mask << HB) | ((1u << HB) - 1u);
+            else collect(Wv);
         }
         clk.lap(2);
         if (RTW_SCAN_SKIP && !any_cand) {                    // no lane has a candidate in this block: nothing to extract
@@ -475,7 +520,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         const unsigned long long act = __ballot(m != 0u);
         if (total + 64u > ws.cap) {
             clk.lap(4);
-            resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig);
+            { unsigned pr[2] = {0u, 0u}; resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig, clk.on() ? pr : nullptr); clk.count(13, total); clk.count(14, pr[0]); clk.count(15, pr[1]); }
             total = 0;
             clk.lap(5);
         }
@@ -489,7 +534,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     }
     }
     if (use_prio) __builtin_amdgcn_s_setprio(sizeof(T) == 4 ? 1 : 0);
-    resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig);
+    { unsigned pr[2] = {0u, 0u}; resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig, clk.on() ? pr : nullptr); clk.count(13, total); clk.count(14, pr[0]); clk.count(15, pr[1]); }
     RTW_PROBE_RESOLVE_TWICE();
     clk.lap(5);
     int idx;
