@@ -87,8 +87,8 @@ N_SIMD, CLOCK_HZ = 1024, 2.4e9
 MFMA_CYCLES_PER_64_TESTS = 4.0  # 4 MFMAs x 32 cycles per block of 32 spheres x 64 rays (2048 tests)
 ALIGNBIT_CYCLES = {"alignbit_2_cycles": 2.0,      # one v_alignbit_b32 per test: the guide's FMA-class issue cost ...
                    "alignbit_4p3_cycles": 4.3}    # ... and the slow-class cost measured on this chip (tools/ubench_rates.hip)
-TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
-PMC_FILE = os.path.join("profiles", "r05_pmc_summary.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_hbm_traffic.json")
+PMC_FILE = os.path.join("profiles", "r06_pmc_summary.json")
 PUBLISHED_MSAMPLES = 1.617      # /root/reference/README.md:86,118-119: 1282.44 s for 1920x1080x1000 spp, Float64, depth 16, 16 threads, Ryzen 3700
 
 

@@ -62,7 +62,7 @@ struct DevCounters {
     unsigned next_job[8];          // one job queue per XCD (claim_job)
     unsigned long long segments;
     unsigned long long samples;
-    unsigned long long phase[16];  // RTW_PHASE_PROFILE=1 only: wave-cycles per phase (s_memtime) [0..5], event counters [6..15]
+    unsigned long long phase[32];  // RTW_PHASE_PROFILE=1 only: wave-cycles per phase (s_memtime) [0..5], event counters [6..31] (tools/valu_budget.py names them)
     unsigned long long t_first, t_last, t_end_sum, n_waves;   // wall clock (100 MHz) of the first wave start, the last wave
                                                               // end and the sum of all wave ends: the end-of-queue drain
     unsigned end_hist[4096];                                  // waves by end time since t_first, 0.25 ms bins (RTW_DRAIN_PROFILE)
@@ -100,13 +100,13 @@ template <typename T> struct WgShared {
 // Phase profiler (opt-in instantiation, never used for timed runs): s_memtime stamps around
 // the phases of the lane loop, summed per wave.
 template <bool ON> struct PhaseClock {
-    unsigned long long t0 = 0, acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t0 = 0, acc[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     __device__ __forceinline__ void start() { if (ON) t0 = __builtin_readcyclecounter(); }
     __device__ __forceinline__ void lap(int k) {
         if (ON) { unsigned long long t = __builtin_readcyclecounter(); acc[k] += t - t0; t0 = t; }
     }
     static constexpr bool on() { return ON; }
-    __device__ __forceinline__ void count(int k, unsigned n) { if (ON) acc[k] += n; }      // event counters in the cells 6 .. 15
+    __device__ __forceinline__ void count(int k, unsigned n) { if (ON) acc[k] += n; }      // event counters in the cells 6 .. 31
 };
 
 __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned s) {
@@ -475,6 +475,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             const bool miss = RTW_PROBE_MISS(has_ray && idx < 0);
             const unsigned long long miss_mask = __ballot(miss);
             if (miss_mask) {
+                clk.count(18, 1u); clk.count(19, (3u * (unsigned)__popcll(miss_mask) + 63u) / 64u);         // H1 executed; its rounds of 64 (lane, channel) tasks
                 unsigned char *scr = reinterpret_cast<unsigned char *>(ws.pairs);
                 double *task_val = reinterpret_cast<double *>(scr);                           // 192 x 8 B
                 unsigned short *task_acc = reinterpret_cast<unsigned short *>(scr + 1536);    // 192 x 2 B: LDS offset of the pixel's accumulators | channel
@@ -508,6 +509,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         const bool need = alive && !hit && samples_left == 0;
         const unsigned long long need_mask = __ballot(need);
         if (need_mask) {
+            clk.count(20, 1u);                                                                            // A executed
             bool last = false;
             if (need && have_item) {
                 last = __hip_atomic_fetch_add(&sh->slot((ref_depth & RTW_REF_MASK) >> 4, P.slot_stride)->remaining, -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
@@ -520,6 +522,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                 fin &= fin - 1ull;
                 JobSlot *S = sh->slot(uniform((unsigned)__shfl((int)((ref_depth & RTW_REF_MASK) >> 4), L)), P.slot_stride);
                 store_job<T>(P, S, lane, out);
+                clk.count(21, 1u);                                                                        // jobs stored
                 __hip_atomic_store(&S->ready_seq, RTW_SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // Items for the lanes that need one: from the wave's current batch; when that runs out (or there is none) the wave draws a
@@ -588,6 +591,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
                     if (!m_mine) break;                                       // the job is not open yet / no slot is free: try again in the next iteration
                     sl = (unsigned)__builtin_ctzll(m_mine);
                     const JobSlot *S = sh->slot(sl, P.slot_stride);
+                    clk.count(22, 1u);                                                                    // batches set up
                     pool_slot = sl; pool_b = tk_b;
                     pool_next = 0; pool_end = 64;
                     have_ticket = false;
@@ -647,6 +651,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
         V3<T> vec = {0, 0, 0};    // PATH_BALL: n (Lambertian) / reflect(d, n) (Metal); PATH_NORM: the raw direction
         T vscale_ = 1;            // PATH_BALL: 1 (Lambertian) / fuzz (Metal)
         int kind = 0;
+        if (PROFILE && __any(hit)) clk.count(23, 1u);                                                    // H2 executed
         if (hit) {
             const V4 g = CULL ? cull.exact[idx] : scene.geom[idx];    // CULL: device order
             const V4 m0 = CULL ? cull.mat0[idx] : scene.mat0[idx];
@@ -684,6 +689,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             samples_left -= 1;
         }
         n_samples += (unsigned long long)__popcll(__ballot(new_sample));
+        if (PROFILE && __any(new_sample)) clk.count(24, 1u);                                             // B executed
 
         // ---- (R) ONE rejection loop for every lane that needs a random point: unit ball for
         //      Lambertian / Metal scatter (src/rand.jl:15-22), unit disk for the lens (:31-38) ----
@@ -704,6 +710,14 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             }
             if (pending) len2 = T(1);
 #else
+            if constexpr (PROFILE) {                     // (the same loop with a wave-uniform trip: R executed, its trials, the trials with a third draw)
+                if (__any(pending)) clk.count(17, 1u);
+                while (__any(pending)) {
+                    clk.count(16, 1u);
+                    if (__any(ball && pending)) clk.count(29, 1u);
+                    if (pending) { len2 = reject_trial<T>(rng, ball, rp); pending = !(len2 <= T(1)); }
+                }
+            }
             while (pending) {
                 len2 = reject_trial<T>(rng, ball, rp);
                 pending = !(len2 <= T(1));
@@ -724,6 +738,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             thr_r = thr_g = thr_b = 1.0;
             ref_depth = (ref_depth & RTW_REF_MASK) | ((unsigned)P.max_depth << RTW_REF_BITS);
         }
+        if (PROFILE && __any(todo == PATH_NORM)) clk.count(25, 1u);                                      // F's normalize executed
         if (todo == PATH_NORM) rd = normalize(vec);
         if (ball || new_sample || todo == PATH_NORM) has_ray = ref_depth > RTW_REF_MASK;   // depth <= 0: ray_color returns 0 (src/ray_color.jl:15)
         clk.lap(1);
@@ -731,7 +746,7 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
     }
 
     if (PROFILE && lane == 0) {
-        for (int k = 0; k < 16; ++k) atomicAdd(&ctr->phase[k], clk.acc[k]);
+        for (int k = 0; k < 32; ++k) atomicAdd(&ctr->phase[k], clk.acc[k]);
     }
     if (lane == 0) {
         // A global atomic is a 32-byte write at the memory side: the waves of a workgroup add up in LDS and the last one to

@@ -242,6 +242,14 @@ int resolve_rec(RenderRec *r, rtw_stats_t *agg) {
                             "lane-iterations lost at batch boundaries %.2f %% (pool short) + %.2f %% (no usable batch)\n", (unsigned long long)c.phase[8],
                     100.0 * (double)c.phase[9] / (64.0 * (double)c.phase[8]), (unsigned long long)c.phase[9], 100.0 * (double)c.phase[10] / (double)c.phase[8],
                     100.0 * (double)c.phase[11] / (64.0 * (double)c.phase[8]), 100.0 * (double)c.phase[12] / (64.0 * (double)c.phase[8]));
+        if (c.phase[8]) {
+            fprintf(stderr, "[rtw phase counts] per wave-iteration:");
+            static const char *nm[32] = {0, 0, 0, 0, 0, 0, "blocks_without_candidate", "blocks", "iterations", "lanes_with_ray", "iterations_without_ray", "takers_pool_short", "takers_unserved",
+                                         "list_entries", "exact_test_rounds", "exact_tests", "reject_trials", "R_executed", "H1_executed", "H1_rounds", "A_executed", "jobs_stored", "batches_set_up",
+                                         "H2_executed", "B_executed", "F_normalize_executed", "sign_collections", "blocks_recording", "explode_iterations", "reject_trials_3_draws", 0, 0};
+            for (int k = 6; k < 32; ++k) if (nm[k]) fprintf(stderr, " %s=%.4f", nm[k], (double)c.phase[k] / (double)c.phase[8]);
+            fprintf(stderr, "\n");
+        }
         if (c.phase[8] && c.phase[13])
             fprintf(stderr, "[rtw phase profile] pass 2: %.1f list entries, %.2f exact-test rounds and %.1f exact tests per wave-iteration (lanes busy in a round: %.1f %%)\n",
                     (double)c.phase[13] / (double)c.phase[8], (double)c.phase[14] / (double)c.phase[8], (double)c.phase[15] / (double)c.phase[8], 100.0 * (double)c.phase[15] / (64.0 * (double)c.phase[14]));

@@ -202,6 +202,7 @@ __device__ __forceinline__ void resolve_pairs_impl(int num, SRC src, [[maybe_unu
         const unsigned code31 = e.y + 31u;
         for (;;) {
             const unsigned long long act = __ballot(m != 0u);
+            if (prof) prof[2] += 1u;                                   // (phase-profile build: iterations of this loop)
             if (!act) break;
             if (total + 64u > ws.cap2) {
                 __builtin_amdgcn_wave_barrier();
@@ -257,7 +258,8 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     const float fq[6] = {dx2 * dx, dy2 * dy, dz2 * dz, (dx2 + dx2) * dy, (dx2 + dx2) * dz, (dy2 + dy2) * dz};
     // a lane that is not ok: all features 0 and t1 = +-60000 (exact in f16): W = +-2^15 x 60000 for EVERY sphere
     const float tx = ok ? tq : (has_ray ? 60000.0f * 32768.0f : -60000.0f * 32768.0f);
-    const uint4 *pa = (CULLED ? mc->ops : w.mf_ops) + lane;
+    const uint4 *ops_base = CULLED ? mc->ops : w.mf_ops;         // (wave-uniform: the block's operands are read as base[block] + lane, no 64-bit vector address arithmetic per block)
+    auto pa_of = [&](int b) { return ops_base + (size_t)(unsigned)b * 128u; };
     const int n_blocks = CULLED ? mc->blocks : w.mf_blocks;
     // Group cull: the block vote.  A sphere of a block can only be hit if the RAY (t >= 0) meets the block's box grown by the margin m
     // (hit_world_cull derives m).  Round 4 ran that slab test per (lane, block): 23 VALU instructions x 17 blocks, about what the skipped
@@ -334,7 +336,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     // (measured: running the first group's vote and the first operand fetch HERE, in front of the ray operands and the huge-sphere tests,
     //  changes nothing -- 293.1 against 293.2 ms -- and costs a spilled register: the vote stays in the block loop's prologue)
     uint4 A1 = {0u, 0u, 0u, 0u}, A2 = {0u, 0u, 0u, 0u};
-    if constexpr (!CULLED) { A1 = pa[0]; A2 = pa[64]; }
+    if constexpr (!CULLED) { A1 = pa_of(0)[lane]; A2 = pa_of(0)[lane + 64u]; }
     // Lane (H, j) supplies slots 8H .. 8H + 7 of both MFMAs for ray j (first half wave: h = 0) / ray 32 + j (h = 1).  Every
     // lane makes, for ITS ray, the operand words of both lane groups; one v_permlane32_swap per word then hands each lane
     // group its words for both half waves:
@@ -428,7 +430,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         if (!todo) continue;
         blk = base + (int)__builtin_ctz(todo);
         todo &= todo - 1u;
-        A1 = pa[blk * 128]; A2 = pa[blk * 128 + 64];
+        A1 = pa_of(blk)[lane]; A2 = pa_of(blk)[lane + 64u];
     }
     for (bool more = true; more;) {
         const int cur = blk;                                   // (this iteration's block; `blk` becomes the next one)
@@ -468,6 +470,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
 #pragma unroll
                     for (int r = r0; r < r0 + GS; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(Wv[r]), 31);
                     any_cand = true;
+                    clk.count(26, 1u);                                                 // sign collections executed (per group)
                 }
             }
         };
@@ -497,7 +500,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
             rtw_f16v Wv = zero;
             if (!CULLED || do_half1) Wv = filter_pair(A1, A2, B1[1], B2[1]);
             __builtin_amdgcn_sched_barrier(0);
-            A1 = pa[blk * 128]; A2 = pa[blk * 128 + 64];
+            A1 = pa_of(blk)[lane]; A2 = pa_of(blk)[lane + 64u];
             __builtin_amdgcn_sched_barrier(0);
             RTW_PROBE_EVAL_TWICE(Wv);
             if (CULLED && !do_half1) mask = (mask << HB) | ((1u << HB) - 1u);
@@ -518,9 +521,10 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         // walks the bits.  (Until round 5 every BIT became an entry here: a loop of ballot / ctz / mbcnt / write per candidate of the
         // busiest lane, ~25 - 35 VALU instructions per block with a candidate against 7 now.)
         const unsigned long long act = __ballot(m != 0u);
+        clk.count(27, 1u);                                                             // blocks that record entries
         if (total + 64u > ws.cap) {
             clk.lap(4);
-            { unsigned pr[2] = {0u, 0u}; resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig, clk.on() ? pr : nullptr); clk.count(13, total); clk.count(14, pr[0]); clk.count(15, pr[1]); }
+            { unsigned pr[3] = {0u, 0u, 0u}; resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig, clk.on() ? pr : nullptr); clk.count(13, total); clk.count(14, pr[0]); clk.count(15, pr[1]); clk.count(28, pr[2]); }
             total = 0;
             clk.lap(5);
         }
@@ -534,7 +538,7 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     }
     }
     if (use_prio) __builtin_amdgcn_s_setprio(sizeof(T) == 4 ? 1 : 0);
-    { unsigned pr[2] = {0u, 0u}; resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig, clk.on() ? pr : nullptr); clk.count(13, total); clk.count(14, pr[0]); clk.count(15, pr[1]); }
+    { unsigned pr[3] = {0u, 0u, 0u}; resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig, clk.on() ? pr : nullptr); clk.count(13, total); clk.count(14, pr[0]); clk.count(15, pr[1]); clk.count(28, pr[2]); }
     RTW_PROBE_RESOLVE_TWICE();
     clk.lap(5);
     int idx;

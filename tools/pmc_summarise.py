@@ -36,16 +36,7 @@ try:
     wc = a["SQ_WAVE_CYCLES"]
     out["derived_f32"].update({"wait_inst_any_frac_of_wave_cycles": a["SQ_WAIT_INST_ANY"] / wc, "active_inst_any_frac_of_wave_cycles": a["SQ_ACTIVE_INST_ANY"] / wc,
                                "issue_busy": (m["SQ_VALU_MFMA_BUSY_CYCLES"] + 2 * a["SQ_INSTS_VALU"]) / (1024 * cyc)})
-    pa, pm_ = out["pmc_f32_pool_sqA"]["counters"], out["pmc_f32_pool_mfma"]["counters"]
-    pb = out["pmc_f32_pool_sqB"]["counters"]
-    pcyc = pa["GRBM_GUI_ACTIVE"] / 8
-    out["derived_f32_pool"] = {"valu_per_wave_segment": pa["SQ_INSTS_VALU"] / (segs / 64), "salu_per_wave_segment": pa["SQ_INSTS_SALU"] / (segs / 64),
-                               "lds_per_wave_segment": pb["SQ_INSTS_LDS"] / (segs / 64), "mfma_per_wave_segment": pm_["SQ_INSTS_MFMA"] / (segs / 64),
-                               "clock_GHz": pcyc / out["pmc_f32_pool_sqA"]["kernel_ns"][0], "mfma_busy_frac_of_simd_cycles": pm_["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * pcyc),
-                               "valu_busy_frac_at_2_cycles": pa["SQ_INSTS_VALU"] * 2 / (1024 * pcyc), "issue_busy": (pm_["SQ_VALU_MFMA_BUSY_CYCLES"] + 2 * pa["SQ_INSTS_VALU"]) / (1024 * pcyc),
-                               "wait_any_frac_of_wave_cycles": pa["SQ_WAIT_ANY"] / pa["SQ_WAVE_CYCLES"], "wait_inst_any_frac_of_wave_cycles": pa["SQ_WAIT_INST_ANY"] / pa["SQ_WAVE_CYCLES"],
-                               "lds_bank_conflict_frac": pm_["SQ_LDS_BANK_CONFLICT"] / max(pm_["SQ_LDS_IDX_ACTIVE"], 1),
-                               "salu_per_wave_segment_lane_loop": a["SQ_INSTS_SALU"] / (segs / 64), "lds_per_wave_segment_lane_loop": out["pmc_f32_sqB"]["counters"]["SQ_INSTS_LDS"] / (segs / 64)}
+    out["derived_f32"].update({"salu_per_wave_segment": a["SQ_INSTS_SALU"] / (segs / 64), "lds_per_wave_segment": out["pmc_f32_sqB"]["counters"]["SQ_INSTS_LDS"] / (segs / 64)})
     ca, cm = out.get("pmc_f32_cull_sqA"), out.get("pmc_f32_cull_mfma")
     if ca and cm:
         ca, cm, ccyc = ca["counters"], cm["counters"], ca["counters"]["GRBM_GUI_ACTIVE"] / 8
