@@ -434,6 +434,13 @@ def host_cpu_info():
         info["model"] = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
     except Exception:
         info["model"] = None
+    info["cgroup_cpus_granted"] = None                            # CFS quota / period: the CPU TIME this container may use, in CPUs
+    try:
+        q, per = (info["cgroup_cpu_max"] or "").split()[:2]
+        if q != "max":
+            info["cgroup_cpus_granted"] = round(float(q) / float(per), 2)
+    except Exception:
+        pass
     return info
 
 
@@ -488,8 +495,10 @@ def cpu_legs(wl, seconds, thread_counts=None):
         l["thread_curve_Msamples_per_s"] = curve
         l["host"] = host
     if len(legs) > 1 and legs[-1]["value"] < 0.9 * best["value"]:
-        best["sample"] += (f"; more threads are SLOWER here ({curve}): the process may use {avail} logical CPUs (cgroup cpu.max: {host['cgroup_cpu_max']}) of a shared host -- "
-                           "beyond the physical cores it is granted the pinned threads share cores (SMT siblings / CFS quota throttling), and the path is latency-bound scalar code")
+        granted = host.get("cgroup_cpus_granted")
+        best["sample"] += (f"; more threads are SLOWER here ({curve}): the process sees {avail} logical CPUs of a shared host, but its cgroup grants it "
+                           + (f"the CPU time of {granted:g} CPUs (cpu.max = {host['cgroup_cpu_max']}): threads beyond that are throttled by the CFS quota and only add scheduling overhead"
+                              if granted else f"a limited share (cpu.max: {host['cgroup_cpu_max']}): more threads share cores / are throttled"))
     return legs, next((l for l in legs if l["cores"] == 16), None)
 
 

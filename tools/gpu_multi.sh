@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=${1:-$R/gpurun_out/multi}; mkdir -p $
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 NG=$(python -c "import torch; print(torch.cuda.device_count())")
 echo "visible devices: $NG"
-timeout 1200 python -m pytest tests/test_gpu_round4.py tests/test_gpu_round5.py -q -k "multi_gpu or gather or rccl or in_library" -rs 2>&1 | tail -8
+timeout 1200 python -m pytest tests/test_gpu_round2.py tests/test_gpu_round4.py tests/test_gpu_round5.py tests/test_gpu_round6.py -q -k "multi_gpu or multi_device or gather or rccl or in_library or shards" -rs 2>&1 | tail -8
 for N in 1 2 4 8; do
   [ $N -le $NG ] || continue
   for C in reduce gather; do

@@ -3,6 +3,8 @@
 #
 #   julia --project=/path/to/RayTracingWeekend.jl -t1 tools/julia_kat.jl > julia_kat.txt
 #   python tools/check_julia_kat.py julia_kat.txt          # prints PASS/FAIL per [UNVERIFIED] item
+#   julia --project=/path/to/RayTracingWeekend.jl -t 16 tools/julia_bench.jl 16 > julia_bench.json     # the reference's CPU path timed (BASELINE.md B1)
+#                                                          # + the first execution of julia/RTWeekendHIP.jl where the library and a GPU exist
 #
 # Output = one record per line, `key: values...`; floats are printed with %.9g (Float32) / %.17g
 # (Float64), which round-trips exactly.  The two images go to julia_render_2spheres_96x54_16spp_<T>.bin
