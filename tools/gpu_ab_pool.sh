@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
-  make -s -C raytracingweekend.jl_amd/csrc -B OUT=/tmp/librtw_$name.so EXTRA="$flags" 2>&1 | grep -E "error"
+  make -s -j8 -C raytracingweekend.jl_amd/csrc -B POOL=1 OUT=/tmp/librtw_$name.so EXTRA="$flags" 2>&1 | grep -E "error"
 done
 for spec in "$@"; do
   name=${spec%%=*}
