@@ -43,9 +43,18 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   scan_valu    -- the same workload with RTW_FLAG_SCAN_VALU (the contract discriminant for every
                   sphere on the vector ALUs, the round-1/2 scan): same image, for comparison.
   cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
-                  bounded sample of the same workload (same image, fewer spp): the faster of a
-                  16-thread leg (`cpu_baseline_16t`, the north star's comparison point) and an
-                  all-threads leg (`cpu_baseline_all_threads`).
+                  bounded sample of the same workload (same image, fewer spp), as a CURVE over thread
+                  counts (16 / 32 / 64 / all; each count in its own process with the threads pinned:
+                  OMP_PLACES=cores OMP_PROC_BIND=close): `cpu_baseline` is the best leg and carries the
+                  curve (`thread_curve_Msamples_per_s`) and what the host grants (`host`: affinity, cgroup
+                  cpu.max -- the GPU boxes of this pool grant 16 CPUs of time, so 16 threads win);
+                  `cpu_baseline_16t` is the north star's comparison point, `cpu_baseline_all_threads` the last leg.
+  small_frames -- the launch- / tail-bound regime: BASELINE configs[0] and configs[1] and the small renders the reference publishes
+                  (src/proto/proto.jl:64-66, :195-200), per CALL of the C entry points with prebuilt structs: median / min / p90 us of 200
+                  host-buffer calls, kernel us, overhead, Msamples/s, fraction of the headline's rate, the device-resident variant,
+                  `vs_published` (other hardware: context).  Its rates are repeated inside `config` (`small_frames_Msamples_per_s`),
+                  `accelerated.value` and `value_end_to_end` inside `roofline`: the driver's record keeps the VALUES of those two objects.
+                  `--small-frames N` runs only this leg.
   accelerated  -- the opt-in RTW_FLAG_GROUP_CULL mode (same image bit for bit), reported separately.
   end_to_end   -- one call of the host-buffer entry point rtw_render_* (scene upload, render,
                   D2H of the image: the PCIe-inclusive rate; never `value`).

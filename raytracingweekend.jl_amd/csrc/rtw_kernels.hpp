@@ -2,9 +2,11 @@
 // pixel accumulation and the gamma / store of src/render.jl:40.  gfx950 only; wave = 64 lanes.
 //
 // Work decomposition
-//   job   = one 4x4 pixel block of an 8x8 tile (2x2 or 1 pixel for small shards) for ALL its sample chunks.  Jobs come
-//           from one global queue (one atomic per job); a job is owned by ONE workgroup, whose
-//           LDS holds the block's 16 x 3 pixel accumulators while the job is in flight.
+//   job   = a block of 16, 8, 4 or 1 pixels of an 8x8 tile (rtw_launch.hip picks the size: 4 normally, 1 for small shards of long
+//           renders, 16 for frames of a handful of jobs per workgroup) for ALL its sample chunks.  Jobs come from one queue per XCD
+//           (claim_job: static first claims, then guided claims through an LDS cache); a job is owned by ONE workgroup, in one of
+//           its job slots in LDS -- header + the pixels' accumulators -- while its items are in flight.  Slots are handed out OUT OF
+//           ORDER: a straggler holds its own slot only (phase A of the lane loop).
 //   item  = (pixel, chunk): `chunk_spp` consecutive samples of one pixel drawn from the item's own
 //           Xoroshiro128+ stream.  64 consecutive items = job pixels x (64 / job pixels) chunks = one wave batch,
 //           taken from the workgroup's ticket counter in LDS.
@@ -12,10 +14,10 @@
 //           its path ends (no lock-step on path length) and takes the next item when its chunk
 //           is finished.  The only convergent part is the sphere scan, which every lane with a
 //           ray executes every iteration.
-//   accum = a finished chunk sum (3 doubles) is added to the job's accumulators EXACTLY (64.64
+//   accum = every sample's radiance (3 doubles) is added to the job's accumulators EXACTLY (64.64
 //           fixed point, LDS integer atomics) -- addition order does not matter, so there is no
 //           per-chunk workspace in HBM and no second kernel: the lane that retires the job's last
-//           item triggers the store of the 16 pixels (sum -> / spp -> sqrt -> RGB{T}).
+//           item triggers the store of the job's pixels (sum -> / spp -> sqrt -> RGB{T}).
 //   Results do not depend on scheduling, grid size, shard count or job-slot availability.
 #pragma once
 #include "rtw_device.hpp"
@@ -44,7 +46,7 @@ struct KParams {
     unsigned total_jobs;   // (64 >> job_shift) * (tiles owned by this shard)
     unsigned local_tiles;  // tiles owned by this shard
     unsigned bpj;          // batches per job = ceil(n_chunks / (64 >> job_shift))
-    unsigned n_slots, slot_stride, div_slots_m, div_slots_s;   // job slots per workgroup (by job size), bytes per slot, n / n_slots
+    unsigned n_slots, slot_stride;          // job slots per workgroup (by job size), bytes per slot
     unsigned job_shift;    // log2(pixels per job): 4, 3, 2 or 0.  A batch = (1 << job_shift) pixels x (64 >> job_shift) chunks.
                            // Smaller jobs = finer load balance at the end of the queue (small shards); same image.
     unsigned rows_shift;   // a job is (1 << rows_shift) rows x (1 << (job_shift - rows_shift)) columns: rows first, because rows are
@@ -71,8 +73,8 @@ struct DevCounters {
 // One job in flight: the bookkeeping of the open/retire protocol and the block header, followed in LDS by
 // the job's pixel accumulators (8 x u64 per pixel: r.lo r.hi g.lo g.hi b.lo b.hi poison pad).
 struct JobSlot {
-    unsigned ready_seq;                      // RTW_SLOT_FREE | RTW_SLOT_OPENING | the job sequence number it holds
-    unsigned job;                            // global job id, or RTW_JOB_EOF (queue exhausted; never freed)
+    unsigned ready_seq;                      // RTW_SLOT_FREE | RTW_SLOT_OPENING_BIT + seq (being opened) | the job sequence number it holds
+    unsigned job;                            // the job's queue position; RTW_JOB_EOF / RTW_JOB_RETRY while open_job reports that there is none (yet)
     int remaining;                           // items of the job not yet finished
     unsigned valid;                          // bit px: pixel px of the block lies inside the image
     int i_base, j_base;                      // 0-based row / column of the block's first pixel
@@ -701,6 +703,9 @@ __global__ __launch_bounds__(256, (TraceWavesOf<T, CULL, MFMA>::value)) void tra
             RTW_PROBE_REJECT_TWICE();
             // (wave priority, Float32 matrix-pipe kernels -- see hit_world_mfma: this loop is pure VALU work, a filler like the block
             //  loop; 364.0 -> 363.0 ms)
+            // (Rejected in round 6, in git history: ending the loop when one lane is still sampling and letting that lane continue its
+            //  trials in the next iteration -- 6.35 -> 5.05 trials per iteration, but 371.2 -> 378.1 ms plain, 285.9 -> 293.4 ms group
+            //  cull, 277.5 -> 282.2 ms Float64: the parked lane sits out a scan and the mask bookkeeping costs 140 scalar instructions.)
             constexpr bool use_prio = MFMA && sizeof(T) == 4 && RTW_SCAN_PRIO != 0;
             if (use_prio) __builtin_amdgcn_s_setprio(0);
 #ifdef RTW_PROBE_REJ_CAP     // (rtw_probes.hpp)

@@ -164,7 +164,6 @@ int launch_render(rtw_scene_handle scene, const CamT *cam, const rtw_params *p, 
     if (env_rows_shift >= 0 && env_rows_shift <= job_shift && env_rows_shift <= 3 && job_shift - env_rows_shift <= 2) K.rows_shift = (unsigned)env_rows_shift;
     K.slot_stride = (unsigned)(sizeof(rtw::JobSlot) + 64u * (1u << job_shift));
     K.n_slots = std::min(24u, (unsigned)RTW_SLOT_BYTES / K.slot_stride);             // 24 / 12 / 7 / 4 slots of 1 / 4 / 8 / 16 pixels
-    make_udiv(K.n_slots, &K.div_slots_m, &K.div_slots_s);
     make_udiv((unsigned)bpj, &K.div_bpj_m, &K.div_bpj_s);
     long long max_useful = (total_jobs * bpj + 3) / 4;                                             // one batch per wave, 4 waves per block
 #ifdef RTW_WITH_POOL
