@@ -48,3 +48,24 @@ def test_more_shards_than_tiles_reports_every_shard(rtw):
     st = rtw.last_stats()
     assert np.array_equal(one, six) and st["samples"] == 16 * 9 * 4
     assert len(st["per_device"]) == 6 and [ms for _, ms in st["per_device"]][4:] == [0.0, 0.0]
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+@pytest.mark.parametrize("job_pixels,spp,n_chunks", [(16, 24, 24), (16, 5, 0), (8, 40, 40), (4, 40, 8), (4, 64, 64), (1, 130, 130), (1, 40, 0)])
+def test_job_slots_with_stragglers(rtw, oracle, T, job_pixels, spp, n_chunks):
+    """Depth 50 in the reference's scene (glass spheres: paths of dozens of bounces next to paths of one), every job size -- 4 slots of 16
+    pixels ... 24 of one --, chunkings with one batch per job and with many: slots are recycled out of order around the stragglers; image,
+    segment and sample counters against the oracle."""
+    rtw.reseed()
+    scene, cam = rtw.scene_random_spheres(elem_type=T), rtw.t_cam1(elem_type=T)
+    W, H = 112, 63
+    flat = rtw.flatten_scene(scene, T)
+    nch = n_chunks or oracle.default_n_chunks(spp)
+    ref, ost = oracle.render(flat, cam, W, H, spp, T=T, max_depth=50, seed=5, n_chunks=nch)
+    from test_gpu_render import gpu_render
+    g = dict(flat=flat, cam={k: np.asarray(getattr(cam, k)) for k in oracle.CAM_FIELDS} | {"lens_radius": np.asarray(cam.lens_radius)},
+             image=np.zeros(1, T), width=W, height=H, spp=spp, depth=50, seed=5, n_chunks=n_chunks)
+    for flags in (0, 1):
+        img, st = gpu_render(g, job_pixels=job_pixels, flags=flags)
+        assert np.array_equal(img, ref), (flags, int((img != ref).sum()))
+        assert st.samples == W * H * spp and st.segments == ost["segments"]
