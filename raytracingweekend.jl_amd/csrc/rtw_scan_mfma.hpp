@@ -101,6 +101,8 @@ struct MfmaCull {
     const void *mat0;     // the cold rows in this (device) order: mat0[i].x = the radius (NUM_REFERENCE_FMA2)
     float glo[3], ghi[3]; // the box of the whole small class (the union of its blocks' boxes): a ray is clipped against it ONCE per scan
     int n_huge;           // spheres (device order) tested in-lane like DevScene::huge -- the huge ones and, when it fits, the whole BIG class: their indices follow the flag words of the first group's tables
+    int n_exact;          // ... of which the first n_exact get the EXACT test in every lane (the huge ones: hit by most rays); the others only the
+                          //     discriminant -- a lane with disc >= 0 records a list entry, pass 2 does the rest (RTW_INLANE_FILTER)
     CullGrid grid;        // the block vote: bins ...
     const unsigned *tab;  // ... and tables (global memory, or the workgroup's copy in LDS)
 };
@@ -134,6 +136,9 @@ __device__ __forceinline__ double lane_get(double v, unsigned src_lane) {
 
 // (Rejected and removed in round 6, in git history: flagging GROUPS of 2 / 4 spheres per list entry -- 380.5 / 388.0 against 370.9 ms, pass 2 pays
 // one exact test per member --, and collecting the signs by v_cmp into SGPR lane masks -- +4.7 %.)
+#ifndef RTW_INLANE_FILTER
+#define RTW_INLANE_FILTER 1     // group cull: the in-lane class beyond the huge spheres gets the discriminant only, candidates go through the list (0: the exact test in every lane, rounds 4 - 5)
+#endif
 #ifndef RTW_PRECHECK_GROUPS
 #define RTW_PRECHECK_GROUPS 1   // groups per half block whose sign collection is skipped separately (hit_world_mfma): 1, 2 or 4
 #endif
@@ -376,11 +381,13 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
     }
     // ---- the result cells, initialised with the lane's own exact test of the scene's huge spheres (DevScene::huge / MfmaCull::huge):
     //      the same contract test and the same key / tie rule as pass 2, so the minimum over all candidates is unchanged ----
+    const unsigned lane_const = lane << 16;
+    unsigned total = 0;                                   // wave-uniform: entries in the wave's candidate list
     {
         unsigned long long key0 = ~0ull;
         [[maybe_unused]] unsigned kidx0 = 0u;
         using V4 = typename Vec4<T>::type;
-        const int n_huge = CULLED ? mc->n_huge : w.n_huge;
+        const int n_huge = CULLED ? (RTW_INLANE_FILTER ? mc->n_exact : mc->n_huge) : w.n_huge;
         for (int hgi = 0; hgi < n_huge; ++hgi) {
             int si;
             if constexpr (CULLED) si = __builtin_amdgcn_readfirstlane((int)mc->tab[6 * RTW_CULL_BINS + 4 + hgi]);      // (the list lies with the vote's tables)
@@ -406,9 +413,35 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         if constexpr (sizeof(T) == 4) ws.keys[lane] = key0;
         else { ws.keys[lane] = key0; ws.kidx[lane] = kidx0; }
     }
-
-    const unsigned lane_const = lane << 16;
-    unsigned total = 0;                                   // wave-uniform
+    // The rest of the in-lane class (group cull: the BIG class's other members -- the unit spheres of the reference's scene, each hit by a
+    // tenth of the rays): every lane evaluates the DISCRIMINANT of the render's numerics for its own ray; where it is >= 0 the lane records
+    // an ordinary list entry for (its ray, that sphere) and pass 2 does the root, the key and the tie rule.  (Until round 6 these spheres
+    // got the whole exact test in every lane: ~48 VALU instructions each per scan against ~26 now.)
+    if constexpr (CULLED && RTW_INLANE_FILTER) {
+        using V4 = typename Vec4<T>::type;
+        for (int hgi = mc->n_exact; hgi < mc->n_huge; ++hgi) {
+            const int si = __builtin_amdgcn_readfirstlane((int)mc->tab[6 * RTW_CULL_BINS + 4 + hgi]);
+            const V4 sg = src[si];
+            T hb_, disc_;
+            T rr_ = T(0);
+            if (w.numerics == NUM_REFERENCE_FMA2) rr_ = rad()[si].x;
+            sphere_disc<T>(w.numerics, sg.x, sg.y, sg.z, sg.w, rr_, o, d, hb_, disc_);
+            const bool cand = has_ray && !(disc_ < T(0));
+            const unsigned long long cm = __ballot(cand);
+            if (cm) {
+                if (total + 64u > ws.cap) { resolve_pairs<T>(w.numerics, src, rad, o, d, tmin, ws, total, lane, orig); total = 0; }
+                if (cand) {
+                    // the entry a recording lane (H, j) would write for ray j + 32 half and sphere 32 block + 16 H + register: H, block, register from
+                    // the sphere, j and the half from this lane
+                    const unsigned b = ((lane >> 5) << 4) | ((unsigned)si & 15u);
+                    const unsigned code = ((((unsigned)si >> 4) & 1u) << 21) | ((lane & 31u) << 16) | (((unsigned)si >> 5) << 5);
+                    const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, total));
+                    reinterpret_cast<uint2 *>(ws.pairs)[pos] = uint2{0x80000000u >> b, code};
+                }
+                total += (unsigned)__popcll(cm);
+            }
+        }
+    }
     // Wave priority: low inside the block loop, raised for everything else (pass 2 and the divergent phases of the lane loop are
     // chains of dependent LDS / VALU instructions; a wave in the block loop issues a 32-cycle MFMA pair and waits for it
     // anyway).  Measured at Float32: 372.1 -> 368.0 ms on one box, 361.8 -> 359.9 on a faster one, group cull 345.6 -> 343.0; which of

@@ -146,7 +146,8 @@ int build_cull(const SceneT *s, rtw_scene_dev *h) {
                 if (!have) rest.push_back(dI);
             }
             // (Float32 only -- measured 293.1 -> 288.9 ms at configs[2]; the binary64 tests cost more than the block: 93.3 -> 93.9 ms at the published configuration)
-            if (sizeof(T) == 4 && h->c_n_inlane + (int)rest.size() <= RTW_CULL_INLANE_MAX)
+            static const bool inlane_f64 = aid_flag("RTW_INLANE_F64");      // (A/B aid: the in-lane class for Float64 too -- with the discriminant-only form of round 6)
+            if ((sizeof(T) == 4 || inlane_f64) && h->c_n_inlane + (int)rest.size() <= RTW_CULL_INLANE_MAX)
                 for (int dI : rest) h->c_inlane[h->c_n_inlane++] = dI;
         }
         auto in_lane = [&](int dI) { for (int j = 0; j < h->c_n_inlane; ++j) if (h->c_inlane[j] == dI) return true; return false; };

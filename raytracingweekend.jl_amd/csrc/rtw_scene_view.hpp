@@ -18,6 +18,7 @@ rtw::CullScene<T> cull_scene_of(const rtw_scene_dev *h) {
     for (int k = 0; k < 3; ++k) { C.mf_glo[k] = h->c_glo[k]; C.mf_ghi[k] = h->c_ghi[k]; }
     static_assert(RTW_CULL_INLANE_MAX == 8, "rtw_scene_dev::c_inlane");
     C.n_huge = h->c_mf_ops ? h->c_n_inlane : 0;
+    C.n_huge_exact = h->c_mf_ops ? std::min(h->n_huge, h->c_n_inlane) : 0;      // (the huge spheres come first in c_inlane)
     for (int k = 0; k < 3; ++k) { C.grid.inv[k] = h->c_grid[k]; C.grid.off[k] = h->c_grid[3 + k]; }
     C.numerics = rtw::NUM_REFERENCE;
     return C;
