@@ -521,23 +521,30 @@ __device__ __forceinline__ int hit_world_mfma(const DevScene<T> &w, SRC src, V3<
         };
         constexpr unsigned HB = 16u;                          // mask bits per half block
         {
-            rtw_f16v Wv = zero;
-            if (!CULLED || do_half0) Wv = filter_pair(A1, A2, B1[0], B2[0]);
-            RTW_PROBE_EVAL_TWICE(Wv);
-            if (CULLED && !do_half0) mask = (1u << HB) - 1u;          // (no ray of this half can touch the block)
-            else collect(Wv);
+            if (!CULLED || do_half0) {
+                rtw_f16v Wv = filter_pair(A1, A2, B1[0], B2[0]);
+                RTW_PROBE_EVAL_TWICE(Wv);
+                collect(Wv);
+            } else {
+                mask = (1u << HB) - 1u;                               // (no ray of this half can touch the block)
+            }
         }
         {
             // the next block's operands are fetched as soon as this block's last use of each is issued (one block of
             // padding at the end), so only one set of A registers is live during the evaluation
-            rtw_f16v Wv = zero;
-            if (!CULLED || do_half1) Wv = filter_pair(A1, A2, B1[1], B2[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            A1 = pa_of(blk)[lane]; A2 = pa_of(blk)[lane + 64u];
-            __builtin_amdgcn_sched_barrier(0);
-            RTW_PROBE_EVAL_TWICE(Wv);
-            if (CULLED && !do_half1) mask = (mask << HB) | ((1u << HB) - 1u);
-            else collect(Wv);
+            // (two copies of the prefetch: with ONE behind an `if (run) Wv = ...` the skipped side zeroes all 16 result registers -- 16 v_mov per
+            //  skipped ray half in the group cull, measured in the ISA)
+            if (!CULLED || do_half1) {
+                rtw_f16v Wv = filter_pair(A1, A2, B1[1], B2[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                A1 = pa_of(blk)[lane]; A2 = pa_of(blk)[lane + 64u];
+                __builtin_amdgcn_sched_barrier(0);
+                RTW_PROBE_EVAL_TWICE(Wv);
+                collect(Wv);
+            } else {
+                A1 = pa_of(blk)[lane]; A2 = pa_of(blk)[lane + 64u];
+                mask = (mask << HB) | ((1u << HB) - 1u);
+            }
         }
         clk.lap(2);
         if (RTW_SCAN_SKIP && !any_cand) {                    // no lane has a candidate in this block: nothing to extract

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "raytracingweekend.jl_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "asm_g")
 KERNEL = "_ZN3rtw12trace_kernelIfLb0ELb1ELb0ELb1ELi0EEE"
+KERNEL_CULL = "_ZN3rtw12trace_kernelIfLb0ELb1ELb1ELb1ELi0EEE"       # `--cull`: the group-cull instance
 
 # phase = (file, anchor substring of the line where it starts); a phase runs to the next anchor of the same file.  `mult`: counter name(s).
 PHASES = [
@@ -38,8 +39,11 @@ PHASES = [
     ("rtw_scan_mfma.hpp", "__device__ __forceinline__ void test_singles(", "S   pass 2: exact test, per round of 64 candidates", "exact_test_rounds", "v_sqrt_f32"),
     ("rtw_scan_mfma.hpp", "__device__ __forceinline__ void resolve_pairs_impl(", "S   pass 2: explode entries into candidates", "explode_iterations", "v_mbcnt_hi"),
     ("rtw_scan_mfma.hpp", "// ---- ray features (binary32) ----", "S   prologue: ray features, f16 splits, operand words", "1"),
+    ("rtw_scan_mfma.hpp", "[[maybe_unused]] auto block_sets = [&]", "S   group cull: clip of the ray + table vote (once per group of 32 blocks)", "1"),
+    ("rtw_scan_mfma.hpp", "// (measured: running the first group's vote and the first operand fetch HERE", "S   prologue: ray features, f16 splits, operand words", "1"),
+    ("rtw_scan_mfma.hpp", "// The rest of the in-lane class (group cull", "S   group cull: discriminant of the in-lane class, list entries", "1"),
     ("rtw_scan_mfma.hpp", "// ---- the result cells, initialised with", "S   prologue: in-lane test of the huge spheres", "1"),
-    ("rtw_scan_mfma.hpp", "const unsigned lane_const = lane << 16;", "S   block loop: control, MFMA issue, AND pre-check", "blocks"),
+    ("rtw_scan_mfma.hpp", "// Wave priority: low inside the block loop", "S   block loop: control, MFMA issue, AND pre-check", "blocks"),
     ("rtw_scan_mfma.hpp", "for (int r = r0; r < r0 + GS; ++r) mask = __builtin_amdgcn_alignbit", "S   block loop: sign collection (16 v_alignbit)", "sign_collections", "v_alignbit_b32/16"),
     ("rtw_scan_mfma.hpp", "any_cand = true;", "S   block loop: control, MFMA issue, AND pre-check", "blocks"),
     ("rtw_scan_mfma.hpp", "// the lanes with a candidate in this block record", "S   block loop: record the block's entries", "blocks_recording"),
@@ -86,6 +90,10 @@ def phase_of(tab, fname, line):
 def main():
     counts = {"1": 1.0, "0": 0.0}
     measured = None
+    global KERNEL
+    if "--cull" in sys.argv:
+        sys.argv.remove("--cull")
+        KERNEL = KERNEL_CULL
     for a in sys.argv[1:]:
         if os.path.exists(a):
             txt = open(a).read()
