@@ -210,6 +210,9 @@ int rtw_stats_devices(int32_t capacity, int32_t *count, int32_t *devices, double
  *       13 hit_world_mfma (pass 1 on the matrix pipe: the trace kernel's plain scan), scene staged in LDS;
  *          tmin of ray 0 serves the whole launch, tmax is +inf
  *       14 the same with block culling (RTW_FLAG_GROUP_CULL on the matrix pipe), cull layout staged in LDS
+ *       15 near_zero(v) (src/vec.jl:19-20)
+ *       16 (Float32) the kernels' short correctly-rounded sqrt / reciprocal against the compiler's IEEE sequences on a range of binary32 bit patterns:
+ *          in = (first pattern, count) per item, out = (mismatches sqrt, mismatches 1/x, first bad pattern of each or -1)
  *   bits 8-9 of `op`: the numerics mode of the ray-sphere test for ops 0, 8 - 11, 13, 14 (0 reference, 1 contract, 3 reference_fma2; 2 is rejected)  */
 int rtw_unit_f32(int op, int count, const void *in, void *out, const rtw_scene_f32 *scene,
                  const rtw_camera_f32 *cam);

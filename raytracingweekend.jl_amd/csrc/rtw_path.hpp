@@ -16,8 +16,43 @@ template <typename T> struct Vec4;
 template <> struct Vec4<float> { using type = float4; };
 template <> struct Vec4<double> { using type = double4; };
 
-__device__ __forceinline__ float t_sqrt(float x) { return __builtin_sqrtf(x); }
+// Correctly rounded binary32 square root and reciprocal in FEWER instructions than the compiler's IEEE expansions (14 / 10 VALU instructions:
+// denormal scaling, v_sqrt / v_rcp, +-1 ulp checks with v_cndmask, fix-ups) -- 5.6 square roots and 2 reciprocals per lane-loop iteration.
+// Markstein's sequences on the hardware approximations (1 ulp): every step an FMA, the last one rounds once.  Valid where nothing under- or
+// overflows on the way: the arguments of a wave are range-checked, and a wave with ANY argument outside takes the compiler's sequence (a
+// tangent ray's discriminant 0, denormals, inf, NaN).  Same bits as __builtin_sqrtf / 1.0f / x for EVERY binary32 argument: unit op 16 compares
+// all 2^32 of them on the device (tests/test_gpu_round6.py).  RTW_EXACT_FAST_MATH=0: the compiler's sequences.
+#ifndef RTW_EXACT_FAST_MATH
+#define RTW_EXACT_FAST_MATH 1
+#endif
+__device__ __forceinline__ float t_sqrt(float x) {
+#if RTW_EXACT_FAST_MATH
+    if (__all(x >= 0x1p-100f && x <= 0x1p100f)) {
+        const float y = __builtin_amdgcn_rsqf(x);
+        float g = x * y, h = 0.5f * y;
+        const float r = __builtin_fmaf(-h, g, 0.5f);
+        g = __builtin_fmaf(g, r, g); h = __builtin_fmaf(h, r, h);
+        const float d = __builtin_fmaf(-g, g, x);
+        return __builtin_fmaf(d, h, g);
+    }
+#endif
+    return __builtin_sqrtf(x);
+}
 __device__ __forceinline__ double t_sqrt(double x) { return __builtin_sqrt(x); }
+// 1 / x, one rounding (StaticArrays' inv(norm(v)))
+__device__ __forceinline__ float t_rcp(float x) {
+#if RTW_EXACT_FAST_MATH
+    if (__all(__builtin_fabsf(x) >= 0x1p-100f && __builtin_fabsf(x) <= 0x1p100f)) {
+        float y = __builtin_amdgcn_rcpf(x);
+        float e = __builtin_fmaf(-x, y, 1.0f);
+        y = __builtin_fmaf(e, y, y);
+        e = __builtin_fmaf(-x, y, 1.0f);
+        return __builtin_fmaf(e, y, y);
+    }
+#endif
+    return 1.0f / x;
+}
+__device__ __forceinline__ double t_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 

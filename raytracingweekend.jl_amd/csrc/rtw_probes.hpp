@@ -118,5 +118,5 @@
 #define RTW_RSQRT(x) ::rtw::probe_rsq(x)
 #else
 #define RTW_DIV(a, b) ((a) / (b))                    // IEEE division
-#define RTW_RSQRT(x) (T(1) / t_sqrt(x))             // StaticArrays: inv(norm(v)), two correctly rounded operations
+#define RTW_RSQRT(x) t_rcp(t_sqrt(x))                // StaticArrays: inv(norm(v)), two correctly rounded operations
 #endif

@@ -16,7 +16,8 @@ enum UnitOp {
     U_HIT_WORLD_MFMA = 13,   // hit_world_mfma (pass 1 on the matrix pipe), scene staged in LDS; tmin / tmax of ray 0 serve the whole launch
     U_HIT_WORLD_MFMA_CULL = 14,   // hit_world_mfma with block culling (RTW_FLAG_GROUP_CULL on the matrix pipe), cull layout staged in LDS
     U_NEAR_ZERO = 15,        // near_zero(v) (src/vec.jl:20): squared length against the Float64 literal 1e-5
-    U_NUM_OPS = 16
+    U_EXACT_MATH = 16,       // t_sqrt / t_rcp against the compiler's IEEE sqrt / division on a RANGE of binary32 bit patterns (Float32 only)
+    U_NUM_OPS = 17
 };
 
 __host__ __device__ inline int unit_in_slots(int op) {
@@ -30,6 +31,7 @@ __host__ __device__ inline int unit_in_slots(int op) {
         case U_SKYCOLOR: return 3;      // d[3]
         case U_RNG: return 2;           // state[2]
         case U_NEAR_ZERO: return 3;     // v[3]
+        case U_EXACT_MATH: return 2;    // first bit pattern, number of consecutive patterns
         case U_HIT_WORLD: case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: case U_HIT_WORLD_MFMA: case U_HIT_WORLD_MFMA_CULL: return 8;     // o[3], d[3], tmin, tmax
         case U_RAY_COLOR: return 9;     // state[2], o[3], d[3], depth
         case U_FX_SUM: return 8;        // 8 binary64 values
@@ -47,6 +49,7 @@ __host__ __device__ inline int unit_out_slots(int op) {
         case U_SKYCOLOR: return 3;
         case U_RNG: return 6;           // state[2], 4 uniforms
         case U_NEAR_ZERO: return 2;     // near_zero(v), squared_length(v) (src/vec.jl:19-20)
+        case U_EXACT_MATH: return 4;    // mismatches of t_sqrt, of t_rcp, first bad pattern of each (or -1)
         case U_HIT_WORLD: case U_HIT_WORLD_LDS: case U_HIT_WORLD_CULL: case U_HIT_WORLD_MFMA: case U_HIT_WORLD_MFMA_CULL: return 9;     // idx, t, p[3], n[3], front
         case U_RAY_COLOR: return 6;     // state[2], colour[3], segments
         case U_FX_SUM: return 2;        // sum, poisoned
@@ -114,6 +117,24 @@ __global__ void unit_kernel(int op, int count, const double *__restrict__ in, do
             Rng rng = {as_u64(x[0]), as_u64(x[1])};
             for (int k = 0; k < 4; ++k) { T u; trand(rng, u); y[2 + k] = (double)u; }
             y[0] = as_f64(rng.x); y[1] = as_f64(rng.y);
+        } break;
+        case U_EXACT_MATH: {
+            // (the waves of this launch see consecutive patterns in their lanes: in-range and out-of-range arguments mix, as in the kernel)
+            double bad_s = 0, bad_r = 0, first_s = -1, first_r = -1;
+            if constexpr (sizeof(T) == 4) {
+                const unsigned p0 = (unsigned)x[0], n = (unsigned)x[1];
+                for (unsigned k = 0; k < n; ++k) {
+                    const unsigned u = p0 + k;
+                    const float v = __uint_as_float(u);
+                    const unsigned a = __float_as_uint(t_sqrt(v)), b = __float_as_uint(__builtin_sqrtf(v));
+                    const unsigned c = __float_as_uint(t_rcp(v)), e = __float_as_uint(1.0f / v);
+                    const bool nan_ab = (a & 0x7fffffffu) > 0x7f800000u && (b & 0x7fffffffu) > 0x7f800000u;      // (any NaN equals any NaN)
+                    const bool nan_ce = (c & 0x7fffffffu) > 0x7f800000u && (e & 0x7fffffffu) > 0x7f800000u;
+                    if (a != b && !nan_ab) { bad_s += 1; if (first_s < 0) first_s = (double)u; }
+                    if (c != e && !nan_ce) { bad_r += 1; if (first_r < 0) first_r = (double)u; }
+                }
+            }
+            y[0] = bad_s; y[1] = bad_r; y[2] = first_s; y[3] = first_r;
         } break;
         case U_NEAR_ZERO: {
             const V3<T> v = ld3<T>(x);

@@ -69,3 +69,16 @@ def test_job_slots_with_stragglers(rtw, oracle, T, job_pixels, spp, n_chunks):
         img, st = gpu_render(g, job_pixels=job_pixels, flags=flags)
         assert np.array_equal(img, ref), (flags, int((img != ref).sum()))
         assert st.samples == W * H * spp and st.segments == ost["segments"]
+
+
+def test_short_sqrt_and_reciprocal_are_correctly_rounded_for_every_binary32():
+    """The kernels' square root and reciprocal (rtw_path.hpp t_sqrt / t_rcp: Markstein's FMA sequences on v_rsq_f32 / v_rcp_f32 inside a range
+    check, the compiler's IEEE sequence outside) against __builtin_sqrtf / 1.0f / x for ALL 2^32 binary32 bit patterns, on the device: the
+    arithmetic of hit(::Sphere)'s root (src/hit.jl:20) and of normalize (src/rand.jl:29, src/camera.jl:46) stays one rounding per operation."""
+    from test_gpu_units import run_unit
+    n_items, per = 1 << 16, 1 << 16
+    x = np.stack([np.arange(n_items, dtype=np.float64) * per, np.full(n_items, per, np.float64)], axis=1)
+    y = run_unit(16, x, 4, np.float32)
+    bad_s, bad_r = int(y[:, 0].sum()), int(y[:, 1].sum())
+    first = [int(v) for v in y[:, 2:].ravel() if v >= 0][:4]
+    assert bad_s == 0 and bad_r == 0, (bad_s, bad_r, [hex(v) for v in first])
